@@ -1,0 +1,135 @@
+/*
+ * mocopci_hip.h -- C ABI of libmocopci_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the point-set hot path of icdm-adteam/MoCoPCI.
+ * Part 1 replaces, one for one, the nine functions the reference registers in its
+ * pybind11 module `pointnet2_cuda` (pointnet2/src/pointnet2_api.cpp:10-24); the
+ * integer argument order of every entry point is the reference wrapper's.
+ * Part 2 is the Python-level second boundary (knn_point, index_points_group,
+ * UpsampleFlow, ... in models/pointconv_util.py and models/m_models/mocopci.py)
+ * expressed as fused kernels.
+ *
+ * Conventions (same contract as the reference extension):
+ *   - all pointers are DEVICE pointers into contiguous fp32 / int32 buffers owned by
+ *     the caller; the library never allocates, frees, or keeps state between calls;
+ *   - every call is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*; NULL = the null stream) and returns without synchronising;
+ *   - re-entrant and thread-safe; the device is the calling thread's current device;
+ *   - return value: 0 on success, otherwise a hipError_t value (launch failure) or
+ *     MCP_ERR_* (argument validation).  The reference calls exit(-1) on launch
+ *     failure (pointnet2/src/sampling_gpu.cu:248-252); this library never exits.
+ */
+#ifndef MOCOPCI_HIP_H
+#define MOCOPCI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mcp_stream_t; /* hipStream_t */
+
+#define MCP_OK 0
+#define MCP_ERR_BAD_ARG 10001     /* null pointer, non-positive dimension */
+#define MCP_ERR_UNSUPPORTED 10002 /* a size outside what the kernels are built for (e.g. K > 32) */
+
+#define MCP_ABI_VERSION 1
+
+int mcp_abi_version(void);
+/* Static string for a code returned by any mcp_* call. */
+const char *mcp_error_string(int code);
+
+/* ---------------- Part 1: pointnet2_cuda replacements ------------------------------ */
+
+/* furthest_point_sampling_wrapper(b,n,m,points,temp,idx)   pointnet2/src/sampling.cpp:38-49,
+ * kernel sampling_gpu.cu:93-253.  xyz (B,N,3); temp (B,N) scratch pre-filled with 1e10 by the
+ * caller (pointnet2_utils.py:26), holds the final min-distances on return; idx (B,M) int32.
+ * Bit-exact with the reference kernel's index sequence including its tie rule. */
+int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx, mcp_stream_t stream);
+
+/* gather_points_wrapper(b,c,n,npoints,points,idx,out)      sampling.cpp:11-22, sampling_gpu.cu:8-44
+ * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */
+int mcp_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx, float *out, mcp_stream_t stream);
+
+/* gather_points_grad_wrapper(b,c,n,npoints,grad_out,idx,grad_points)  sampling.cpp:25-35,
+ * sampling_gpu.cu:46-83.  grad_points (B,C,N) must be zeroed by the caller (pointnet2_utils.py:67). */
+int mcp_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int *idx, float *grad_points,
+                           mcp_stream_t stream);
+
+/* group_points_wrapper(b,c,n,npoints,nsample,points,idx,out)  group_points.cpp:26-37,
+ * group_points_gpu.cu:47-86.  points (B,C,N), idx (B,npoints,nsample) -> out (B,C,npoints,nsample). */
+int mcp_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                     mcp_stream_t stream);
+
+/* group_points_grad_wrapper(b,c,n,npoints,nsample,grad_out,idx,grad_points)  group_points.cpp:11-23,
+ * group_points_gpu.cu:8-44.  grad_points pre-zeroed by the caller (pointnet2_utils.py:190). */
+int mcp_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                          float *grad_points, mcp_stream_t stream);
+
+/* ball_query_wrapper(b,n,m,radius,nsample,new_xyz,xyz,idx)   ball_query.cpp:16-28, ball_query_gpu.cu:9-67
+ * new_xyz (B,M,3) centres, xyz (B,N,3) -> idx (B,M,nsample), pre-zeroed by the caller
+ * (pointnet2_utils.py:218): first nsample hits in index order, padded with the first hit. */
+int mcp_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                   mcp_stream_t stream);
+
+/* three_nn_wrapper(b,n,m,unknown,known,dist2,idx)            interpolate.cpp:14-24, interpolate_gpu.cu:9-74
+ * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) SQUARED distances, idx (B,n,3). */
+int mcp_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, mcp_stream_t stream);
+
+/* three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)   interpolate.cpp:27-39, interpolate_gpu.cu:77-117
+ * points (B,C,M), idx/weight (B,n,3) -> out (B,C,n). */
+int mcp_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out,
+                          mcp_stream_t stream);
+
+/* three_interpolate_grad_wrapper(b,c,n,m,grad_out,idx,weight,grad_points)  interpolate.cpp:42-56,
+ * interpolate_gpu.cu:120-161.  grad_points (B,C,M) pre-zeroed by the caller (pointnet2_utils.py:146). */
+int mcp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
+                               float *grad_points, mcp_stream_t stream);
+
+/* ---------------- Part 2: fused layer operators ------------------------------------ */
+
+/* Distance forms for mcp_knn. */
+#define MCP_DIST_EXPANSION 0 /* -2 q.r + |q|^2 + |r|^2 : square_distance, mocopci.py:1130-1155 */
+#define MCP_DIST_DIRECT 1    /* sum (q-r)^2 : pytorch3d.ops.knn_points (pointconv_util.py:910) */
+
+/* knn_point(nsample, xyz, new_xyz) (mocopci.py:1158-1169 = pointconv_util.py:129-140) and
+ * pytorch3d.ops.knn_points(p1,p2,K) fused: never materialises the (B,Q,N) distance matrix.
+ * query (B,Q,3), ref (B,N,3) -> idx (B,Q,K) int32 and, if dist != NULL, dist (B,Q,K):
+ * the K smallest under the lexicographic order (distance, index), ascending.  1 <= K <= 32.
+ * If N < K the tail repeats the last valid entry. */
+int mcp_knn(int b, int q, int n, int k, int dist_form, const float *query, const float *ref, int *idx, float *dist,
+            mcp_stream_t stream);
+
+/* index_points_group / index_points_gather (mocopci.py:1190-1215) without the permute copies:
+ * points (B,N,C) channel-last, idx (B,T) -> out (B,T,C) (T = S*K or S), whole C*4-byte rows. */
+int mcp_group_rows(int b, int n, int c, int t, const float *points, const int *idx, float *out, mcp_stream_t stream);
+
+/* UpsampleFlow.forward (mocopci.py:1485-1502) / the interpolation half of PointWarping (:1472-1479):
+ * dense (B,N,3), sparse (B,S,3), feat (B,S,C) channel-last -> out (B,N,C);
+ * 3-NN in expansion form, weights 1/max(||d||,1e-10) normalised.  idx3 (int32) and w3 (B,N,3) are
+ * caller-provided outputs (the library holds no workspace); callers can reuse them for further
+ * feature tensors on the same (dense, sparse) pair via mcp_interp3_apply. */
+int mcp_interp3(int b, int n, int s, int c, const float *dense, const float *sparse, const float *feat, float *out, int *idx3,
+                float *w3, mcp_stream_t stream);
+int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, const int *idx3, const float *w3, float *out,
+                      mcp_stream_t stream);
+
+/* chamfer_loss (models/utils.py:36-45 -> pytorch3d chamfer_distance defaults): per-point squared
+ * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
+int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
+
+/* ---------------- Instrumentation (bench.py roofline leg) --------------------------- */
+/* When enabled for a kernel id, each launch of that kernel is bracketed by hipEvents on the launch
+ * stream; mcp_prof_collect synchronises those events and returns launches and total milliseconds.
+ * Off by default; not used on the product path. */
+#define MCP_KERNEL_FPS 1
+#define MCP_KERNEL_KNN 2
+#define MCP_KERNEL_GROUP_ROWS 3
+#define MCP_KERNEL_INTERP3 4
+#define MCP_KERNEL_KNN_COSINE 5
+int mcp_prof_enable(int kernel_id); /* 0 disables */
+int mcp_prof_collect(int *launches, float *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCOPCI_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libmocopci_hip.so (C ABI declared in include/mocopci_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or a tensor is not a
+contiguous CUDA(HIP) tensor of the right dtype, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmocopci_hip.so")
+
+_i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mocopci_hip.h
+SIGNATURES = {
+    "mcp_abi_version": [],
+    "mcp_error_string": [_i],
+    "mcp_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
+    "mcp_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
+    "mcp_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
+    "mcp_group_points": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "mcp_group_points_grad": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "mcp_ball_query": [_i, _i, _i, _f, _i, _p, _p, _p, _p],
+    "mcp_three_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_three_interpolate": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_three_interpolate_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_knn": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_group_rows": [_i, _i, _i, _i, _p, _p, _p, _p],
+    "mcp_interp3": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_prof_enable": [_i],
+    "mcp_prof_collect": [_p, _p],
+}
+_RESTYPES = {"mcp_error_string": ctypes.c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises with a build hint if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} not found: build it with `make -C mocopci_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        lib = ctypes.CDLL(SO_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _i)
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mcp_error_string(rc)
+        raise RuntimeError(f"libmocopci_hip: error {rc}: {msg.decode() if msg else '?'}")
+
+
+def fptr(t):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"expected a contiguous float32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def iptr(t):
+    if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise RuntimeError(f"expected a contiguous int32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

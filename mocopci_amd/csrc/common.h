@@ -1,0 +1,72 @@
+// common.h -- shared device helpers for libmocopci_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mocopci_hip.h"
+
+#define MCP_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ---- floating-point canon (must match oracle/pointset_oracle.c; built with -ffp-contract=off) ----
+// sum of three squared differences: fma(dz,dz, fma(dy,dy, dx*dx))
+__device__ __forceinline__ float mcp_sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+// |p|^2 as torch.sum(p ** 2, -1): rounded squares, sequential sum
+__device__ __forceinline__ float mcp_sqnorm3(float x, float y, float z) { return (x * x + y * y) + z * z; }
+// square_distance expansion form (mocopci.py:1152-1154): (-2*dot + |q|^2) + |r|^2
+__device__ __forceinline__ float mcp_expdist(float qx, float qy, float qz, float qn, float rx, float ry, float rz, float rn) {
+    float dot = __builtin_fmaf(qz, rz, __builtin_fmaf(qy, ry, qx * rx));
+    return __builtin_fmaf(-2.0f, dot, qn) + rn;
+}
+
+// monotone float -> uint32 map (total order incl. negatives; -0 < +0)
+__device__ __forceinline__ uint32_t mcp_ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float mcp_unord(uint32_t u) {
+    u ^= ((u >> 31) - 1u) | 0x80000000u;
+    return __uint_as_float(u);
+}
+
+// ---- DPP helpers (wave64; row = 16 lanes) ----
+template <int CTRL>
+__device__ __forceinline__ uint32_t mcp_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// max over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ uint32_t mcp_row_max_u32(uint32_t v) {
+    uint32_t t;
+    t = mcp_dpp<0xB1>(v);  v = v > t ? v : t;  // quad_perm [1,0,3,2]
+    t = mcp_dpp<0x4E>(v);  v = v > t ? v : t;  // quad_perm [2,3,0,1]
+    t = mcp_dpp<0x141>(v); v = v > t ? v : t;  // row_half_mirror
+    t = mcp_dpp<0x140>(v); v = v > t ? v : t;  // row_mirror
+    return v;
+}
+// max over the whole wave, returned wave-uniform
+__device__ __forceinline__ uint32_t mcp_wave_max_u32(uint32_t v) {
+    v = mcp_row_max_u32(v);
+    uint32_t a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+    uint32_t c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+    a = a > b ? a : b;
+    c = c > d ? c : d;
+    return a > c ? a : c;
+}
+
+// ---- host-side helpers ----
+struct McpProf;
+void mcp_prof_begin(int kernel_id, hipStream_t s);
+void mcp_prof_end(int kernel_id, hipStream_t s);
+
+#define MCP_CHECK_ARGS(cond) \
+    do {                     \
+        if (!(cond)) return MCP_ERR_BAD_ARG; \
+    } while (0)
+
+static inline int mcp_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MCP_OK : (int)e;
+}
+static inline unsigned mcp_divup(unsigned a, unsigned b) { return (a + b - 1) / b; }

@@ -1,0 +1,100 @@
+// interp3.hip -- fused 3-NN inverse-distance interpolation (UpsampleFlow, mocopci.py:1485-1502;
+// the interpolation half of PointWarping, :1472-1479) on channel-last tensors.
+// The reference runs knn_point(3) (materialised (B,N,S) matrix + topk), two K5 gathers with their
+// permute copies, a norm, and a weighted sum: 10+ launches per call, 59 calls per forward.
+// Here: the K<=4 path of knn.hip, one tiny weight kernel, one vectorised row-blend kernel; the
+// (idx3, w3) pair is returned so repeated calls on the same (dense, sparse) pair skip the search.
+#include "common.h"
+
+namespace {
+constexpr int BLK = 256;
+
+// weights from the DISTANCE of the gathered differences (not the squared expansion distance):
+//   dist = clamp(||sparse[idx]-dense||, 1e-10); w = (1/dist) / sum(1/dist)      mocopci.py:1495-1498
+__global__ __launch_bounds__(BLK) void interp3_weights_kernel(int n, int s, const float *__restrict__ dense,
+                                                              const float *__restrict__ sparse, const int *__restrict__ idx3,
+                                                              float *__restrict__ w3) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * BLK + threadIdx.x;
+    if (p >= n) return;
+    const float *x = dense + ((size_t)b * n + p) * 3;
+    const int *id = idx3 + ((size_t)b * n + p) * 3;
+    const float x0 = x[0], x1 = x[1], x2 = x[2];
+    float inv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float *y = sparse + ((size_t)b * s + id[j]) * 3;
+        const float dx = y[0] - x0, dy = y[1] - x1, dz = y[2] - x2;
+        float nr = sqrtf((dx * dx + dy * dy) + dz * dz);
+        nr = nr < 1e-10f ? 1e-10f : nr;
+        inv[j] = 1.0f / nr;
+    }
+    const float nrm = (inv[0] + inv[1]) + inv[2];
+    float *w = w3 + ((size_t)b * n + p) * 3;
+    w[0] = inv[0] / nrm;
+    w[1] = inv[1] / nrm;
+    w[2] = inv[2] / nrm;
+}
+
+// out[b,p,:] = (w0*f[i0,:] + w1*f[i1,:]) + w2*f[i2,:]   (rounded products, sequential sum: torch.sum over dim 2)
+template <typename VT, int VW>
+__global__ __launch_bounds__(BLK) void interp3_apply_kernel(int n, int s, int cv, long long total, const VT *__restrict__ feat,
+                                                            const int *__restrict__ idx3, const float *__restrict__ w3,
+                                                            VT *__restrict__ out) {
+    long long g = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long stride = (long long)gridDim.x * BLK;
+    for (; g < total; g += stride) {
+        const long long row = g / cv;  // b*n + p
+        const int col = (int)(g - row * cv);
+        const int b = (int)(row / n);
+        const int *id = idx3 + row * 3;
+        const float *w = w3 + row * 3;
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+        const VT f0 = feat[((long long)b * s + id[0]) * cv + col];
+        const VT f1 = feat[((long long)b * s + id[1]) * cv + col];
+        const VT f2 = feat[((long long)b * s + id[2]) * cv + col];
+        VT o;
+        const float *a0 = reinterpret_cast<const float *>(&f0);
+        const float *a1 = reinterpret_cast<const float *>(&f1);
+        const float *a2 = reinterpret_cast<const float *>(&f2);
+        float *oo = reinterpret_cast<float *>(&o);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) oo[e] = (w0 * a0[e] + w1 * a1[e]) + w2 * a2[e];
+        out[g] = o;
+    }
+}
+}  // namespace
+
+MCP_EXPORT int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, const int *idx3, const float *w3, float *out,
+                                 mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && s > 0 && c > 0 && feat && idx3 && w3 && out);
+    hipStream_t st = (hipStream_t)stream;
+    const bool al16 = ((((uintptr_t)feat) | ((uintptr_t)out)) & 15) == 0;
+    if (c % 4 == 0 && al16) {
+        const int cv = c / 4;
+        const long long total = (long long)b * n * cv;
+        const unsigned grid = (unsigned)min((total + BLK - 1) / BLK, 8192LL);
+        hipLaunchKernelGGL((interp3_apply_kernel<float4, 4>), dim3(grid), dim3(BLK), 0, st, n, s, cv, total,
+                           reinterpret_cast<const float4 *>(feat), idx3, w3, reinterpret_cast<float4 *>(out));
+    } else {
+        const long long total = (long long)b * n * c;
+        const unsigned grid = (unsigned)min((total + BLK - 1) / BLK, 8192LL);
+        hipLaunchKernelGGL((interp3_apply_kernel<float, 1>), dim3(grid), dim3(BLK), 0, st, n, s, c, total, feat, idx3, w3, out);
+    }
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_interp3(int b, int n, int s, int c, const float *dense, const float *sparse, const float *feat, float *out,
+                           int *idx3, float *w3, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && s > 0 && c > 0 && dense && sparse && feat && out && idx3 && w3);
+    hipStream_t st = (hipStream_t)stream;
+    mcp_prof_begin(MCP_KERNEL_INTERP3, st);
+    int rc = mcp_knn(b, n, s, 3, MCP_DIST_EXPANSION, dense, sparse, idx3, nullptr, stream);
+    if (rc == MCP_OK) {
+        hipLaunchKernelGGL(interp3_weights_kernel, dim3(mcp_divup(n, BLK), b), dim3(BLK), 0, st, n, s, dense, sparse, idx3, w3);
+        rc = mcp_launch_status();
+    }
+    if (rc == MCP_OK) rc = mcp_interp3_apply(b, n, s, c, feat, idx3, w3, out, stream);
+    mcp_prof_end(MCP_KERNEL_INTERP3, st);
+    return rc;
+}

@@ -1,0 +1,288 @@
+// pointnet2_ops.hip -- gather / group / ball_query / three_nn / three_interpolate (+ grads)
+// for gfx950.  Replaces pointnet2/src/{sampling_gpu.cu:8-83, group_points_gpu.cu,
+// ball_query_gpu.cu, interpolate_gpu.cu}.  All are HBM/L2-bound index or copy kernels:
+// one index load is shared across channels, outputs are written coalesced, the per-query
+// scans (ball_query, three_nn) stream the reference points through LDS tiles that every
+// lane reads as a broadcast.
+#include "common.h"
+
+namespace {
+
+constexpr int BLK = 256;
+
+// K2  out[b,c,m] = points[b,c,idx[b,m]]           sampling_gpu.cu:8-24
+__global__ __launch_bounds__(BLK) void gather_points_kernel(int c, int n, int m, const float *__restrict__ points,
+                                                            const int *__restrict__ idx, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * BLK + threadIdx.x;
+    if (p >= m) return;
+    const int src = idx[(size_t)b * m + p];
+    const float *pb = points + (size_t)b * c * n;
+    float *ob = out + (size_t)b * c * m;
+    for (int ci = 0; ci < c; ++ci) ob[(size_t)ci * m + p] = pb[(size_t)ci * n + src];
+}
+
+// K3  grad_points[b,c,idx[b,m]] += grad_out[b,c,m]  sampling_gpu.cu:46-63
+__global__ __launch_bounds__(BLK) void gather_points_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                                                 const int *__restrict__ idx, float *__restrict__ grad_points) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * BLK + threadIdx.x;
+    if (p >= m) return;
+    const int dst = idx[(size_t)b * m + p];
+    const float *gb = grad_out + (size_t)b * c * m;
+    float *pb = grad_points + (size_t)b * c * n;
+    for (int ci = 0; ci < c; ++ci) atomicAdd(pb + (size_t)ci * n + dst, gb[(size_t)ci * m + p]);
+}
+
+// K5  out[b,c,s,k] = points[b,c,idx[b,s,k]]        group_points_gpu.cu:47-66
+// blockIdx.y walks channel chunks of CCH so small-C calls still fill the chip.
+constexpr int CCH = 8;
+__global__ __launch_bounds__(BLK) void group_points_kernel(int c, int n, int sk, const float *__restrict__ points,
+                                                           const int *__restrict__ idx, float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const int e = blockIdx.x * BLK + threadIdx.x;
+    if (e >= sk) return;
+    const int c0 = blockIdx.y * CCH;
+    const int c1 = min(c, c0 + CCH);
+    const int src = idx[(size_t)b * sk + e];
+    const float *pb = points + (size_t)b * c * n;
+    float *ob = out + (size_t)b * c * sk;
+    for (int ci = c0; ci < c1; ++ci) ob[(size_t)ci * sk + e] = pb[(size_t)ci * n + src];
+}
+
+// K6  group_points_gpu.cu:8-25
+__global__ __launch_bounds__(BLK) void group_points_grad_kernel(int c, int n, int sk, const float *__restrict__ grad_out,
+                                                                const int *__restrict__ idx, float *__restrict__ grad_points) {
+    const int b = blockIdx.z;
+    const int e = blockIdx.x * BLK + threadIdx.x;
+    if (e >= sk) return;
+    const int c0 = blockIdx.y * CCH;
+    const int c1 = min(c, c0 + CCH);
+    const int dst = idx[(size_t)b * sk + e];
+    const float *gb = grad_out + (size_t)b * c * sk;
+    float *pb = grad_points + (size_t)b * c * n;
+    for (int ci = c0; ci < c1; ++ci) atomicAdd(pb + (size_t)ci * n + dst, gb[(size_t)ci * sk + e]);
+}
+
+// Channel-last row gather: out[b,t,:] = points[b, idx[b,t], :]   (index_points_group, mocopci.py:1204-1215)
+template <typename VT, int VW>
+__global__ __launch_bounds__(BLK) void group_rows_kernel(int n, int cv, long long total, int t, const VT *__restrict__ points,
+                                                         const int *__restrict__ idx, VT *__restrict__ out) {
+    // cv = C / VW vector columns per row; total = B * t * cv
+    long long g = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long stride = (long long)gridDim.x * BLK;
+    for (; g < total; g += stride) {
+        const long long row = g / cv;
+        const int col = (int)(g - row * cv);
+        const int b = (int)(row / t);
+        const int src = idx[row];
+        out[g] = points[((long long)b * n + src) * cv + col];
+    }
+}
+
+// K4  ball_query_gpu.cu:9-45.  Lane per centre; xyz streamed through an LDS tile; a wave stops
+// scanning once all of its lanes have nsample hits (the reference breaks per thread).
+constexpr int BQ_TILE = 1024;
+__global__ __launch_bounds__(BLK) void ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
+                                                         const float *__restrict__ xyz, int *__restrict__ idx) {
+    __shared__ float tile[BQ_TILE * 3];
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * BLK + threadIdx.x;
+    const bool live = p < m;
+    const float *q = new_xyz + ((size_t)b * m + (live ? p : 0)) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float *rb = xyz + (size_t)b * n * 3;
+    int *o = idx + ((size_t)b * m + (live ? p : 0)) * nsample;
+    int cnt = live ? 0 : nsample;
+    for (int base = 0; base < n; base += BQ_TILE) {
+        const int len = min(BQ_TILE, n - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len * 3; i += BLK) tile[i] = rb[(size_t)base * 3 + i];
+        __syncthreads();
+        if (__syncthreads_and(cnt >= nsample)) break;
+        for (int k = 0; k < len; ++k) {
+            if (!__builtin_amdgcn_ballot_w64(cnt < nsample)) break;
+            const float d2 = mcp_sqdist3(qx, qy, qz, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
+            if (cnt < nsample && d2 < radius2) {
+                if (cnt == 0)
+                    for (int l = 0; l < nsample; ++l) o[l] = base + k;
+                o[cnt] = base + k;
+                ++cnt;
+            }
+        }
+    }
+}
+
+// K7  interpolate_gpu.cu:9-52.  Lane per unknown point; known points through an LDS tile.
+constexpr int NN_TILE = 1024;
+__global__ __launch_bounds__(BLK) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+                                                       const float *__restrict__ known, float *__restrict__ dist2,
+                                                       int *__restrict__ idx) {
+    __shared__ float tile[NN_TILE * 3];
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * BLK + threadIdx.x;
+    const bool live = p < n;
+    const float *u = unknown + ((size_t)b * n + (live ? p : 0)) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const float *kb = known + (size_t)b * m * 3;
+    // the reference keeps doubles initialised to 1e40 that only ever hold floats: (float)1e40 = +inf,
+    // and "d < 1e40" == "d < +inf" for every float d, so float accumulators are exact.
+    float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
+    int besti1 = 0, besti2 = 0, besti3 = 0;
+    for (int base = 0; base < m; base += NN_TILE) {
+        const int len = min(NN_TILE, m - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len * 3; i += BLK) tile[i] = kb[(size_t)base * 3 + i];
+        __syncthreads();
+        for (int k = 0; k < len; ++k) {
+            const float d = mcp_sqdist3(ux, uy, uz, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
+            const int kk = base + k;
+            if (d < best1) {
+                best3 = best2; besti3 = besti2;
+                best2 = best1; besti2 = besti1;
+                best1 = d; besti1 = kk;
+            } else if (d < best2) {
+                best3 = best2; besti3 = besti2;
+                best2 = d; besti2 = kk;
+            } else if (d < best3) {
+                best3 = d; besti3 = kk;
+            }
+        }
+    }
+    if (live) {
+        float *od = dist2 + ((size_t)b * n + p) * 3;
+        int *oi = idx + ((size_t)b * n + p) * 3;
+        od[0] = best1; od[1] = best2; od[2] = best3;
+        oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+    }
+}
+
+// K8  interpolate_gpu.cu:77-97   out[b,c,p] = w0*P[i0] + w1*P[i1] + w2*P[i2]  (canon: two fmas)
+__global__ __launch_bounds__(BLK) void three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
+                                                                const int *__restrict__ idx, const float *__restrict__ weight,
+                                                                float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const int p = blockIdx.x * BLK + threadIdx.x;
+    if (p >= n) return;
+    const int c0 = blockIdx.y * CCH;
+    const int c1 = min(c, c0 + CCH);
+    const int *id = idx + ((size_t)b * n + p) * 3;
+    const float *w = weight + ((size_t)b * n + p) * 3;
+    const int i0 = id[0], i1 = id[1], i2 = id[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    for (int ci = c0; ci < c1; ++ci) {
+        const float *pt = points + ((size_t)b * c + ci) * m;
+        out[((size_t)b * c + ci) * n + p] = __builtin_fmaf(w2, pt[i2], __builtin_fmaf(w1, pt[i1], w0 * pt[i0]));
+    }
+}
+
+// K9  interpolate_gpu.cu:120-142
+__global__ __launch_bounds__(BLK) void three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                                                     const int *__restrict__ idx, const float *__restrict__ weight,
+                                                                     float *__restrict__ grad_points) {
+    const int b = blockIdx.z;
+    const int p = blockIdx.x * BLK + threadIdx.x;
+    if (p >= n) return;
+    const int c0 = blockIdx.y * CCH;
+    const int c1 = min(c, c0 + CCH);
+    const int *id = idx + ((size_t)b * n + p) * 3;
+    const float *w = weight + ((size_t)b * n + p) * 3;
+    const int i0 = id[0], i1 = id[1], i2 = id[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    for (int ci = c0; ci < c1; ++ci) {
+        const float g = grad_out[((size_t)b * c + ci) * n + p];
+        float *gp = grad_points + ((size_t)b * c + ci) * m;
+        atomicAdd(gp + i0, g * w0);
+        atomicAdd(gp + i1, g * w1);
+        atomicAdd(gp + i2, g * w2);
+    }
+}
+
+}  // namespace
+
+MCP_EXPORT int mcp_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx, float *out,
+                                 mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && c > 0 && n > 0 && npoints > 0 && points && idx && out);
+    hipLaunchKernelGGL(gather_points_kernel, dim3(mcp_divup(npoints, BLK), b), dim3(BLK), 0, (hipStream_t)stream, c, n, npoints,
+                       points, idx, out);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int *idx, float *grad_points,
+                                      mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && c > 0 && n > 0 && npoints > 0 && grad_out && idx && grad_points);
+    hipLaunchKernelGGL(gather_points_grad_kernel, dim3(mcp_divup(npoints, BLK), b), dim3(BLK), 0, (hipStream_t)stream, c, n,
+                       npoints, grad_out, idx, grad_points);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                                mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && c > 0 && n > 0 && npoints > 0 && nsample > 0 && points && idx && out);
+    const int sk = npoints * nsample;
+    hipLaunchKernelGGL(group_points_kernel, dim3(mcp_divup(sk, BLK), mcp_divup(c, CCH), b), dim3(BLK), 0, (hipStream_t)stream, c, n,
+                       sk, points, idx, out);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                                     float *grad_points, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && c > 0 && n > 0 && npoints > 0 && nsample > 0 && grad_out && idx && grad_points);
+    const int sk = npoints * nsample;
+    hipLaunchKernelGGL(group_points_grad_kernel, dim3(mcp_divup(sk, BLK), mcp_divup(c, CCH), b), dim3(BLK), 0, (hipStream_t)stream,
+                       c, n, sk, grad_out, idx, grad_points);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_group_rows(int b, int n, int c, int t, const float *points, const int *idx, float *out, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && c > 0 && t > 0 && points && idx && out);
+    hipStream_t s = (hipStream_t)stream;
+    mcp_prof_begin(MCP_KERNEL_GROUP_ROWS, s);
+    const bool al16 = ((((uintptr_t)points) | ((uintptr_t)out)) & 15) == 0;
+    if (c % 4 == 0 && al16) {
+        const int cv = c / 4;
+        const long long total = (long long)b * t * cv;
+        const unsigned grid = (unsigned)min((long long)mcp_divup((unsigned)min(total, (long long)0x7fffffff), BLK), 8192LL);
+        hipLaunchKernelGGL((group_rows_kernel<float4, 4>), dim3(grid), dim3(BLK), 0, s, n, cv, total, t,
+                           reinterpret_cast<const float4 *>(points), idx, reinterpret_cast<float4 *>(out));
+    } else {
+        const long long total = (long long)b * t * c;
+        const unsigned grid = (unsigned)min((long long)mcp_divup((unsigned)min(total, (long long)0x7fffffff), BLK), 8192LL);
+        hipLaunchKernelGGL((group_rows_kernel<float, 1>), dim3(grid), dim3(BLK), 0, s, n, c, total, t, points, idx, out);
+    }
+    mcp_prof_end(MCP_KERNEL_GROUP_ROWS, s);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                              mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && m > 0 && nsample > 0 && new_xyz && xyz && idx);
+    const float radius2 = radius * radius;  // ball_query_gpu.cu:20
+    hipLaunchKernelGGL(ball_query_kernel, dim3(mcp_divup(m, BLK), b), dim3(BLK), 0, (hipStream_t)stream, n, m, radius2, nsample,
+                       new_xyz, xyz, idx);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                            mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && m > 0 && unknown && known && dist2 && idx);
+    hipLaunchKernelGGL(three_nn_kernel, dim3(mcp_divup(n, BLK), b), dim3(BLK), 0, (hipStream_t)stream, n, m, unknown, known, dist2,
+                       idx);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                     float *out, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && c > 0 && m > 0 && n > 0 && points && idx && weight && out);
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3(mcp_divup(n, BLK), mcp_divup(c, CCH), b), dim3(BLK), 0, (hipStream_t)stream, c,
+                       m, n, points, idx, weight, out);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
+                                          float *grad_points, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && c > 0 && m > 0 && n > 0 && grad_out && idx && weight && grad_points);
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(mcp_divup(n, BLK), mcp_divup(c, CCH), b), dim3(BLK), 0,
+                       (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+    return mcp_launch_status();
+}

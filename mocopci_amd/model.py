@@ -1,0 +1,399 @@
+"""Inference graph of models.m_models.mocopci.MoCoPCI (reference mocopci.py:1062-1097) on the
+MI355X point-set operators.
+
+This is the caller of the hot path, re-expressed -- not copied -- on
+channel-last tensors: xyz (B,N,3), features (B,N,C).  The point-set half (FPS, KNN, grouping,
+3-NN interpolation, cost volumes, PointConv, fusion) goes through mocopci_amd.ops; the dense
+half (EI cross-formers, frame attention, MLPs) stays on PyTorch-ROCm dense ops.
+
+State-dict compatibility: the parameter tree is generated from state_dict_spec.json (names,
+shapes, dtypes of the reference's 487 state-dict entries, including modules the reference
+constructs but never calls: fusion_gru, recurrent0, rf_block0, deconv1_0), so a reference
+checkpoint's ['net'] loads with load_state_dict(strict=True).
+
+Differences from the reference graph that do not change out_lst:
+  * the two encoder passes run as one 2B batch; forward/backward decoder directions run as one
+    2B batch; the three level-0 refinements run as one 3B batch (every layer is per-sample in
+    eval mode, so batching is exact);
+  * dead work is skipped: the up_feat*_lst upsamples, the third cross() of cross3, the frames
+    bookkeeping lists used only by the training loss;
+  * identical 3-NN searches on the same (dense, sparse) pair are done once and reused.
+Eval-mode semantics only (BatchNorm running stats, dropout/drop-path off), as the goldens are.
+"""
+import json
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+_SPEC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "state_dict_spec.json")
+LEAKY = 0.1  # mocopci.py:1107, pointconv_util.py:10
+
+
+def leaky(x):
+    return F.leaky_relu(x, LEAKY)
+
+
+class _Node(nn.Module):
+    pass
+
+
+def _dtype(name):
+    return getattr(torch, name)
+
+
+class MoCoPCI(nn.Module):
+    T_F = [0.0, 0.41666666666666663, 0.5, 0.5833333333333333, 1.0]  # mocopci.py:824
+    T_B = [1.0, 0.5833333333333333, 0.5, 0.41666666666666663, 0.0]  # mocopci.py:825
+
+    def __init__(self):
+        super().__init__()
+        with open(_SPEC_PATH) as fh:
+            self._spec = json.load(fh)
+        for name, meta in self._spec.items():
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = getattr(node, p)
+            t = torch.zeros(meta["shape"], dtype=_dtype(meta["dtype"]))
+            if meta["buffer"]:
+                node.register_buffer(parts[-1], t)
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(t))
+        self._cache = None
+        self.eval()
+
+    # ---- parameter access ---------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._cache = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._cache = None
+        return super().load_state_dict(*a, **k)
+
+    def _params(self):
+        if self._cache is None:
+            c = {}
+            for n, p in self.named_parameters():
+                c[n] = p.detach()
+            for n, b in self.named_buffers():
+                c[n] = b
+            self._cache = c
+            self._time_cache = {}
+        return self._cache
+
+    def W(self, name):
+        """weight of a 1x1 conv / linear as (out,in)."""
+        w = self._params()[name + ".weight"]
+        return w.reshape(w.shape[0], -1)
+
+    def Bv(self, name):
+        return self._params().get(name + ".bias")
+
+    def lin(self, x, name):
+        return F.linear(x, self.W(name), self.Bv(name))
+
+    def conv1d_block(self, x, name):
+        """Conv1d wrapper of the reference (mocopci.py:1111-1127): 1x1 conv + LeakyReLU(0.1)."""
+        return leaky(self.lin(x, name + ".composed_module.0"))
+
+    def bn_eval(self, x, name, eps):
+        """BatchNorm in eval mode on a channel-last tensor."""
+        P = self._params()
+        scale = P[name + ".weight"] * torch.rsqrt(P[name + ".running_var"] + eps)
+        return (x - P[name + ".running_mean"]) * scale + P[name + ".bias"]
+
+    # ---- point-set layers ---------------------------------------------------------------
+    def pointconv(self, prefix, s_xyz, new_xyz, s_points, nsample=32):
+        """PointConv / PointConvD body after sampling (mocopci.py:1315-1346, :1362-1396; group /
+        group_query :1218-1266; WeightNet :1289-1300)."""
+        be = ops.backend()
+        B, S, _ = new_xyz.shape
+        idx = be.knn(new_xyz, s_xyz, nsample)
+        g_xyz = be.group_rows(s_xyz, idx) - new_xyz.unsqueeze(2)          # (B,S,K,3)
+        g_pts = be.group_rows(s_points, idx)                              # (B,S,K,D)
+        new_points = torch.cat([g_xyz, g_pts], dim=-1)                    # (B,S,K,3+D)
+        w = g_xyz
+        for i in range(3):
+            w = F.relu(self.lin(w, f"{prefix}.weightnet.mlp_convs.{i}"))  # (B,S,K,8)
+        agg = torch.matmul(new_points.transpose(2, 3), w)                 # (B,S,3+D,8)
+        return leaky(self.lin(agg.reshape(B, S, -1), prefix + ".linear"))
+
+    def pointconv_d(self, prefix, npoint, xyz, points):
+        be = ops.backend()
+        fps_idx = be.fps(xyz, npoint)
+        new_xyz = be.group_rows(xyz, fps_idx)                             # (B,npoint,3)
+        return new_xyz, self.pointconv(prefix, xyz, new_xyz, points)
+
+    def run_encoder(self, xyz):
+        """PointConvEncoder.forward (mocopci.py:438-468), color == xyz."""
+        p = "encoder."
+        f0 = self.conv1d_block(xyz, p + "level0_lift")
+        f0 = self.pointconv(p + "level0", xyz, xyz, f0)
+        f0_1 = self.conv1d_block(f0, p + "level0_1")
+        pc1, f1 = self.pointconv_d(p + "level1", 2048, xyz, f0_1)
+        f1 = self.conv1d_block(f1, p + "level1_0")
+        f1_2 = self.conv1d_block(f1, p + "level1_1")
+        pc2, f2 = self.pointconv_d(p + "level2", 512, pc1, f1_2)
+        f2 = self.conv1d_block(f2, p + "level2_0")
+        f2_3 = self.conv1d_block(f2, p + "level2_1")
+        pc3, f3 = self.pointconv_d(p + "level3", 256, pc2, f2_3)
+        f3 = self.conv1d_block(f3, p + "level3_0")
+        f3_4 = self.conv1d_block(f3, p + "level3_1")
+        pc4, f4 = self.pointconv_d(p + "level4", 64, pc3, f3_4)
+        return [xyz, pc1, pc2, pc3, pc4], [f0, f1, f2, f3, f4]
+
+    def cross(self, xyz1, xyz2, points1, points2, knn1, knn2, pos, mlp, sorted_p3d):
+        """cost-volume cross() (pointconv_util.py:750-781; :894-922 with pytorch3d knn_points;
+        :1126-1161).  16 feature-cosine neighbours then 16 xyz neighbours of set 2 per point of
+        set 1, LeakyReLU(g2 + p1 + pos(dxyz)), 1x1 convs, max over the 32 neighbours."""
+        be = ops.backend()
+        idx_c = be.knn_cosine(knn1, knn2, 16)
+        if sorted_p3d:
+            # pointconv_util.py:910-911: knn_points(xyz2, xyz1) -- QUERY = xyz2, REF = xyz1 -- and the
+            # resulting indices (into xyz1) are then used to index set 2.  Reproduced as is.
+            idx_p = be.knn(xyz2, xyz1, 16, mode=ops.MCP_DIST_DIRECT)
+        else:
+            idx_p = be.knn(xyz1, xyz2, 16)
+        idx = torch.cat([idx_c, idx_p], dim=-1)                           # (B,N1,32)
+        direction = be.group_rows(xyz2, idx) - xyz1.unsqueeze(2)          # (B,N1,32,3)
+        g2 = be.group_rows(points2, idx)                                  # (B,N1,32,D)
+        x = leaky((g2 + points1.unsqueeze(2)) + self.lin(direction, pos))
+        for name in mlp:
+            x = leaky(self.lin(x, name + ".composed_module.0"))
+        return x.max(dim=2)[0]
+
+    def interp(self, dense, sparse, feat, cache=None, key=None):
+        """UpsampleFlow (mocopci.py:1485-1502) with search reuse on a keyed (dense, sparse) pair."""
+        be = ops.backend()
+        if cache is None:
+            return be.interp3(dense, sparse, feat)
+        if key not in cache:
+            cache[key] = be.interp3_search(dense, sparse)
+        idx3, w3 = cache[key]
+        return be.interp3_apply(feat, idx3, w3)
+
+    def warp(self, xyz1, xyz2, flow1):
+        """PointWarping.forward (mocopci.py:1458-1482)."""
+        return xyz2 - ops.backend().interp3(xyz2, xyz1 + flow1, flow1)
+
+    # ---- dense blocks (callers; PyTorch dense ops) ---------------------------------------
+    def cross_attention(self, prefix, x, c, heads=8):
+        """CrossAttention.forward (mocopci.py:72-86)."""
+        B, N, C = x.shape
+        kv = self.lin(c, prefix + ".kv").reshape(B, N, 2, heads, C // heads).permute(2, 0, 3, 1, 4)
+        q = self.lin(x, prefix + ".q").reshape(B, N, heads, C // heads).permute(0, 2, 1, 3)
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1])
+        return self.lin(o.transpose(1, 2).reshape(B, N, C), prefix + ".proj")
+
+    def layer_norm(self, x, name):
+        P = self._params()
+        return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], 1e-6)
+
+    def ei_crossformer(self, prefix, x1, x2):
+        """EI_Crossformer.forward (mocopci.py:147-151): Injector(x1,x2) | Extractor(x2,x1) -> pj."""
+        P = self._params()
+        i, e = prefix + ".injector", prefix + ".extractor"
+        res1 = P[i + ".gamma"] * self.cross_attention(i + ".attn", self.layer_norm(x1, i + ".query_norm"),
+                                                      self.layer_norm(x2, i + ".feat_norm"))
+        q = x2 + self.cross_attention(e + ".attn", self.layer_norm(x2, e + ".query_norm"), self.layer_norm(x1, e + ".feat_norm"))
+        h = self.layer_norm(q, e + ".ffn_norm")
+        res2 = self.lin(F.gelu(self.lin(h, e + ".ffn.fc1")), e + ".ffn.fc2")
+        return F.linear(torch.cat([res1, res2], dim=-1), self.W(prefix + ".pj"))
+
+    def cross_frame_att(self, prefix, x):
+        """Cross_Frame_Att.forward (mocopci.py:499-522) batched over samples.  x (B,2,N,C) holds the two
+        frames' features; the block's attention runs 4 heads of width C and sums over the two frames,
+        so its 4 head slots come out as 4 'frames' (mocopci.py:619-621); the first is dropped."""
+        B, Fr, N, C = x.shape
+        P = self._params()
+        xn = self.bn_eval(x, prefix + ".norm1", 1e-5)
+        xr = torch.flip(xn, dims=[1])
+        a = prefix + ".attn_feats"
+        q = self.lin(xn, a + ".q").reshape(B, Fr, N, 4, C).permute(0, 1, 3, 2, 4)
+        kv = self.lin(xr, a + ".kv").reshape(B, Fr, N, 2, 4, C).permute(3, 0, 1, 4, 2, 5)
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=C ** -0.5)      # (B,2,4,N,C)
+        o = self.lin(o.sum(dim=1), a + ".proj")                                   # (B,4,N,C)
+        t = prefix + ".trans_block_2"
+        xa = self.lin(F.prelu(self.lin(o, t + ".fc1"), P[t + ".act.weight"]), t + ".fc2")
+        frames = self.lin(xa, prefix + ".mapping_xyz")
+        return xa[:, 1:], frames[:, 1:]                                           # (B,3,N,C), (B,3,N,3)
+
+    def mlp_t(self, prefix, x):
+        """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2."""
+        P = self._params()
+        h = self.lin(x, prefix + ".fc1")
+        h = h * P[prefix + ".dwconv.dwconv.weight"].reshape(-1) + P[prefix + ".dwconv.dwconv.bias"]
+        return self.lin(F.prelu(h, P[prefix + ".act.weight"]), prefix + ".fc2")
+
+    def multi_frame_att(self, prefix, x, heads=8):
+        """Multi_Frame_Att.forward (mocopci.py:551-575) batched.  x (B,5,N,C)."""
+        B, Fr, N, C = x.shape
+        xn = self.bn_eval(x, prefix + ".norm1", 1e-5)
+        xr = torch.flip(xn, dims=[1])
+        a = prefix + ".attn_feats"
+        hd = C // heads
+        q = self.lin(xn, a + ".q").reshape(B, Fr, N, heads, hd).permute(0, 1, 3, 2, 4)
+        kv = self.lin(xr, a + ".kv").reshape(B, Fr, N, 2, heads, hd).permute(3, 0, 1, 4, 2, 5)
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1])                       # (B,5,H,N,hd)
+        o = self.lin(o.permute(0, 1, 3, 2, 4).reshape(B, Fr, N, C), a + ".proj")
+        xn = xn + o
+        xb = self.mlp_t(prefix + ".mlp", self.bn_eval(xn, prefix + ".norm2", 1e-5))
+        x = x + xb
+        xf = self.mlp_t(prefix + ".trans_block", x)                               # (B,5,N,latent)
+        frames = self.lin(xf, prefix + ".mapping_xyz")                            # (B,5,N,3)
+        return xf[:, 1:-1], frames[:, 1:-1]
+
+    def time_code(self, ts, dim, device):
+        """Multiframe_Attention.time_embedding (mocopci.py:172-180): float64 python math, stored fp32."""
+        key = (tuple(ts), dim, str(device))
+        if key not in self._time_cache:
+            enc = torch.zeros(len(ts), dim)
+            for i, t in enumerate(ts):
+                for j in range(0, dim, 2):
+                    enc[i, j] = math.sin(t * math.pow(10000, -j / dim))
+                    if j + 1 < dim:
+                        enc[i, j + 1] = math.cos(t * math.pow(10000, -(j + 1) / dim))
+            self._time_cache[key] = enc.to(device)
+        return self._time_cache[key]
+
+    def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc):
+        """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C)."""
+        c1 = torch.cat([f1_0, f1_1, f1_new], dim=-1)
+        c2 = torch.cat([f2_0, f2_1, f2_new], dim=-1)
+        b, fe = prefix + ".bid", prefix + ".fe"
+        t11_1, t22_2 = self.lin(c1, b + ".cross_t11"), self.lin(c2, b + ".cross_t22")
+        t11_2, t22_1 = self.lin(c2, b + ".cross_t11"), self.lin(c1, b + ".cross_t22")
+        bid_mlp = [b + ".mlp.0"]
+        fe_mlp = [fe + ".mlp.0"]
+        fes = []
+        for up in up_frames:
+            pc2w = self.warp(pc1, pc2, up)
+            n1 = self.cross(pc1, pc2w, t11_1, t22_2, f1_0, f2_0, b + ".pos", bid_mlp, True)
+            n2 = self.cross(pc2w, pc1, t11_2, t22_1, f2_0, f1_0, b + ".pos", bid_mlp, True)
+            fes.append(self.cross(pc1, pc2w, self.lin(n1, fe + ".conv1"), self.lin(n2, fe + ".conv2"), f1_0, f2_0,
+                                  fe + ".pos", fe_mlp, False))
+        x = torch.stack([n1, *fes, n2], dim=1) + time_enc                          # (B,5,N,C)
+        xf, frames = self.multi_frame_att(prefix + ".cross_block", x)              # (B,3,N,latent),(B,3,N,3)
+        feat_frames = self.conv1d_block(xf, prefix + ".downsample")                # (B,3,N,C)
+        return frames, n1, n2, feat_frames
+
+    def transformer_block(self, prefix, feats, xyz, k=16):
+        """TransformerBlock.forward (pointT_layer2.py:58-77): vector attention over the 16 nearest
+        neighbours (direct squared distance; the reference's full argsort is replaced by the KNN kernel)."""
+        be = ops.backend()
+        idx = be.knn(xyz, xyz, k, mode=ops.MCP_DIST_DIRECT)
+        knn_xyz = be.group_rows(xyz, idx)
+        x = self.lin(feats, prefix + ".fc1")
+        q = self.lin(x, prefix + ".w_qs")
+        kk = be.group_rows(self.lin(x, prefix + ".w_ks").contiguous(), idx)
+        v = be.group_rows(self.lin(x, prefix + ".w_vs").contiguous(), idx)
+        pos = self.lin(F.relu(self.lin(xyz.unsqueeze(2) - knn_xyz, prefix + ".fc_delta.0")), prefix + ".fc_delta.2")
+        g = (q.unsqueeze(2) - kk) + pos
+        attn = self.lin(F.relu(self.lin(g, prefix + ".fc_gamma.0")), prefix + ".fc_gamma.2")
+        attn = F.softmax(attn / math.sqrt(kk.shape[-1]), dim=-2)
+        res = torch.sum(attn * (v + pos), dim=2)
+        return self.lin(res, prefix + ".fc2") + feats
+
+    def fusion(self, p1, p2, k=32):
+        """MultiFrameEstimatier.knn_group + fusion (mocopci.py:798-819).  p1, p2 (B,N,3)."""
+        be = ops.backend()
+        m = "multi_frame_inference.conv."
+        idx = torch.cat([be.knn(p1, p1, k), be.knn(p1, p2, k)], dim=-1)            # (B,N,2k) both index p2
+        nb = be.group_rows(p2, idx)                                                # (B,N,2k,3)
+        resi = nb - p1.unsqueeze(2)
+        x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)      # (B,N,2k,4)
+        for ci, bi in ((0, 1), (3, 4), (6, 7)):
+            x = F.relu(self.bn_eval(self.lin(x, m + str(ci)), m + str(bi), 1e-3))
+        w = F.softmax(x.max(dim=-1)[0], dim=-1)                                    # (B,N,2k)
+        return torch.sum(w.unsqueeze(-1) * nb, dim=2)                              # (B,N,3)
+
+    # ---- decoder ------------------------------------------------------------------------
+    def run_decoder(self, pcs, feats, B):
+        """MultiFrameEstimatier.forward (mocopci.py:821-1059).  pcs/feats hold both frames stacked on
+        the batch axis (frame 1 = [:B], frame 2 = [B:]).  Returns out_lst: 3 x (B,N,3)."""
+        m = "multi_frame_inference."
+        dev = pcs[0].device
+        sw = lambda t: torch.cat([t[B:], t[:B]], dim=0)                            # swap the two frames
+        pcs_o = [sw(p) for p in pcs]                                               # "other" frame, same order
+        feats_o = [sw(f) for f in feats]
+        cache = {}
+
+        # EI cross-formers (mocopci.py:830-836): fusion features are shared by both frames
+        fus = [None]
+        for lvl, name in ((1, "ei1"), (2, "ei2"), (3, "ei3")):
+            f = self.ei_crossformer(m + name, feats[lvl][:B], feats[lvl][B:])
+            fus.append(torch.cat([f, f], dim=0))
+
+        # l4 -> l3 (mocopci.py:842-845)
+        f_l4_3 = self.conv1d_block(self.interp(pcs[3], pcs[4], feats[4], cache, "43"), m + "deconv4_3")
+        c3 = torch.cat([feats[3], fus[3], f_l4_3], dim=-1)                         # (2B,256,576)
+        c3_o = sw(c3)
+        # cross3 (pointconv_util.py:783-791): rows [:B] give feat1_new, rows [B:] give feat2_new
+        x = m + "cross3"
+        new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(c3_o, x + ".cross_t22"), feats[3],
+                          feats_o[3], x + ".pos1", [x + ".mlp1.0"], False)
+        new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
+        # cross_block3, both directions at once (mocopci.py:853-856)
+        xs = torch.stack([new3, sw(new3)], dim=1)                                  # (2B,2,N3,C)
+        feats3s, frame3s = self.cross_frame_att(m + "cross_block3", xs)            # (2B,3,N3,C),(2B,3,N3,3)
+        f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
+
+        def level(prefix, lvl, f_up, frames_prev, key):
+            ups = [self.interp(pcs[lvl], pcs[lvl + 1], frames_prev[:, i].contiguous(), cache, key) for i in range(3)]
+            C = feats[lvl].shape[-1]
+            te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
+                           dim=0).unsqueeze(2)                                      # (2B,5,1,C)
+            return self.multiframe_attention(prefix, pcs[lvl], pcs_o[lvl], f_up, sw(f_up), feats[lvl], fus[lvl], feats_o[lvl],
+                                             fus[lvl], ups, te)
+
+        # l2 (mocopci.py:870-911): rows [:B] = forward direction, rows [B:] = backward direction
+        frame2s, n1_2, n2_2, feats2s = level(m + "multi_frame_up_2", 2, f_l3_2, frame3s, "32")
+        # l2 -> l1 (mocopci.py:920-927): the forward branch upsamples (feat1_new_f -> pc1, feat2_new_f -> pc2),
+        # the backward branch (feat1_new_b -> pc1, feat2_new_b -> pc2) where *_b come from the swapped call.
+        f1_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n1_2[:B], n2_2[:B]], 0), cache, "21"), m + "deconv2_1")
+        f2_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n2_2[B:], n1_2[B:]], 0), cache, "21"), m + "deconv2_1")
+        # forward call gets (feat1_l2_1_f, feat2_l2_1_f); backward call gets (feat2_l2_1_b, feat1_l2_1_b)
+        f_up_1 = torch.cat([f1_up[:B], f2_up[B:]], dim=0)
+        f_up_1_o = torch.cat([f1_up[B:], f2_up[:B]], dim=0)
+        ups = [self.interp(pcs[1], pcs[2], frame2s[:, i].contiguous(), cache, "21") for i in range(3)]
+        C = feats[1].shape[-1]
+        te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
+                       dim=0).unsqueeze(2)
+        frame1s, _, _, _ = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
+                                                     feats_o[1], fus[1], ups, te)  # (2B,3,N1,3)
+
+        # l0 (mocopci.py:997-1053).  Output frames 0,1 use the forward branch (flow index i on frame 1);
+        # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).
+        flow_src = torch.cat([frame1s[:B, 0], frame1s[:B, 1], frame1s[B:, 0]], dim=0).contiguous()      # (3B,N1,3)
+        pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
+        pc1_ = torch.cat([pcs[1][:B], pcs[1][:B], pcs[1][B:]], dim=0)
+        f0 = torch.cat([feats[0][:B], feats[0][:B], feats[0][B:]], dim=0)
+        up_flow = ops.backend().interp3(pc0, pc1_, flow_src)                       # (3B,N,3)
+        warped = pc0 + up_flow
+        # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022)
+        wf = f0 + F.adaptive_avg_pool1d(up_flow, f0.shape[-1])
+        wf = self.conv1d_block(wf, m + "rlevel0")
+        down, dfeat = self.pointconv_d(m + "level1", 2048, warped, wf)
+        shape = self.transformer_block(m + "shape1", dfeat, down)
+        upf = ops.backend().interp3(warped, down, shape)
+        refine = self.lin(F.relu(self.lin(upf, m + "pred.0")), m + "pred.2")       # (3B,N,3)
+        final = self.fusion(warped, refine)
+        return [final[:B], final[B:2 * B], final[2 * B:]]
+
+    def forward(self, xyz1, xyz2, gt=None, t=None, train=False):
+        """MoCoPCI.forward (mocopci.py:1069-1097): xyz1, xyz2 (B,3,N) -> out_lst, 3 x (B,N,3)."""
+        if train:
+            raise NotImplementedError("inference graph only (train=True needs the backward kernels: SURVEY 8(f) #3)")
+        B = xyz1.shape[0]
+        xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
+        with torch.no_grad():
+            pcs, feats = self.run_encoder(xyz)
+            return self.run_decoder(pcs, feats, B)

@@ -1,0 +1,138 @@
+"""Layer-level point-set operators of the hot path on channel-last tensors, backed by
+libmocopci_hip.so.  These are the fused counterparts of the reference's Python helpers
+(models/m_models/mocopci.py:1130-1266,1456-1502; models/pointconv_util.py:67-192) that the
+model harness (mocopci_amd/model.py) is written against.
+
+Layout convention: xyz (B,N,3), features (B,N,C) -- one neighbour = one contiguous row --
+instead of the reference's (B,C,N); indices are int32 end to end.
+
+`HipBackend` is the product path.  The harness resolves operators through `backend()` so
+that tests and bench.py's cpu_baseline leg can run the SAME graph on the CPU oracle by
+calling `set_backend(...)`; nothing in this package imports the oracle, and HipBackend has
+no CPU fallback (a CPU tensor raises).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+MCP_DIST_EXPANSION = 0
+MCP_DIST_DIRECT = 1
+
+
+def _call(name, ref_tensor, *args):
+    lib = _lib.load()
+    with torch.cuda.device(ref_tensor.device):
+        _lib.check(getattr(lib, name)(*args, _lib.stream()))
+
+
+class HipBackend:
+    name = "hip"
+
+    def fps(self, xyz, npoint):
+        """furthest_point_sample (pointnet2_utils.py:10-29): xyz (B,N,3) -> (B,npoint) int32."""
+        B, N, _ = xyz.shape
+        out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        _call("mcp_furthest_point_sampling", xyz, B, N, npoint, _lib.fptr(xyz), _lib.fptr(temp), _lib.iptr(out))
+        return out
+
+    def knn(self, query, ref, k, mode=MCP_DIST_EXPANSION, return_dist=False):
+        """knn_point(k, ref, query) (mocopci.py:1158-1169): (B,Q,3),(B,N,3) -> (B,Q,k) int32,
+        ascending by (distance, index)."""
+        B, Q, _ = query.shape
+        N = ref.shape[1]
+        idx = torch.empty((B, Q, k), dtype=torch.int32, device=query.device)
+        dist = torch.empty((B, Q, k), dtype=torch.float32, device=query.device) if return_dist else None
+        _call("mcp_knn", query, B, Q, N, k, mode, _lib.fptr(query), _lib.fptr(ref), _lib.iptr(idx),
+              _lib.fptr(dist) if return_dist else None)
+        return (idx, dist) if return_dist else idx
+
+    def knn_cosine(self, qfeat, rfeat, k):
+        """knn_point_cosine(k, rfeat, qfeat) (pointconv_util.py:111-153) on channel-last features.
+        Interim: dense contraction through torch (rocBLAS) + topk; the sets are small here
+        (N <= 2048).  See DESIGN.md for the MFMA kernel that replaces it."""
+        qn = qfeat / torch.sqrt(torch.sum(qfeat ** 2, -1, keepdim=True) + 1e-8)
+        rn = rfeat / torch.sqrt(torch.sum(rfeat ** 2, -1, keepdim=True) + 1e-8)
+        dist = 1.0 - torch.bmm(qn, rn.transpose(1, 2))
+        return torch.topk(dist, k, dim=-1, largest=False, sorted=False)[1].int()
+
+    def group_rows(self, points, idx):
+        """index_points_group / index_points_gather (mocopci.py:1190-1215): points (B,N,C),
+        idx (B,...) int32 -> (B,...,C)."""
+        B, N, C = points.shape
+        idx = idx.contiguous()
+        T = idx[0].numel()
+        out = torch.empty((*idx.shape, C), dtype=torch.float32, device=points.device)
+        _call("mcp_group_rows", points, B, N, C, T, _lib.fptr(points), _lib.iptr(idx), _lib.fptr(out))
+        return out
+
+    def interp3_search(self, dense, sparse):
+        """3-NN search + inverse-distance weights of UpsampleFlow (mocopci.py:1494-1498)."""
+        B, N, _ = dense.shape
+        S = sparse.shape[1]
+        idx3 = torch.empty((B, N, 3), dtype=torch.int32, device=dense.device)
+        w3 = torch.empty((B, N, 3), dtype=torch.float32, device=dense.device)
+        # the C entry point needs a feature tensor; interpolating the sparse coordinates themselves
+        # is the cheapest valid one (C=3) and its output is discarded
+        scratch = torch.empty((B, N, 3), dtype=torch.float32, device=dense.device)
+        _call("mcp_interp3", dense, B, N, S, 3, _lib.fptr(dense), _lib.fptr(sparse), _lib.fptr(sparse), _lib.fptr(scratch),
+              _lib.iptr(idx3), _lib.fptr(w3))
+        return idx3, w3
+
+    def interp3_apply(self, feat, idx3, w3):
+        B, N, _ = idx3.shape
+        S, C = feat.shape[1], feat.shape[2]
+        out = torch.empty((B, N, C), dtype=torch.float32, device=feat.device)
+        _call("mcp_interp3_apply", feat, B, N, S, C, _lib.fptr(feat), _lib.iptr(idx3), _lib.fptr(w3), _lib.fptr(out))
+        return out
+
+    def interp3(self, dense, sparse, feat):
+        """UpsampleFlow.forward (mocopci.py:1485-1502): dense (B,N,3), sparse (B,S,3), feat (B,S,C) -> (B,N,C)."""
+        B, N, _ = dense.shape
+        S, C = feat.shape[1], feat.shape[2]
+        idx3 = torch.empty((B, N, 3), dtype=torch.int32, device=dense.device)
+        w3 = torch.empty((B, N, 3), dtype=torch.float32, device=dense.device)
+        out = torch.empty((B, N, C), dtype=torch.float32, device=dense.device)
+        _call("mcp_interp3", dense, B, N, S, C, _lib.fptr(dense), _lib.fptr(sparse), _lib.fptr(feat), _lib.fptr(out),
+              _lib.iptr(idx3), _lib.fptr(w3))
+        return out
+
+    def chamfer(self, x, y):
+        """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor."""
+        B, N, _ = x.shape
+        M = y.shape[1]
+        dxy = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        dyx = torch.empty((B, M), dtype=torch.float32, device=x.device)
+        _call("mcp_chamfer_nn", x, B, N, M, _lib.fptr(x), _lib.fptr(y), _lib.fptr(dxy), _lib.fptr(dyx))
+        return (dxy.mean(1) + dyx.mean(1)).mean()
+
+
+_backend = HipBackend()
+
+
+def backend():
+    return _backend
+
+
+def set_backend(b):
+    """Swap the operator backend (tests / cpu_baseline only). Returns the previous one."""
+    global _backend
+    prev, _backend = _backend, b
+    return prev
+
+
+# ---- instrumentation passthrough (bench.py) ----
+KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4}
+
+
+def prof_enable(kernel_name):
+    _lib.check(_lib.load().mcp_prof_enable(KERNEL_IDS.get(kernel_name, 0) if kernel_name else 0))
+
+
+def prof_collect():
+    n = ctypes.c_int(0)
+    ms = ctypes.c_float(0.0)
+    _lib.check(_lib.load().mcp_prof_collect(ctypes.byref(n), ctypes.byref(ms)))
+    return n.value, ms.value

@@ -1,0 +1,45 @@
+"""oracle/backend.py -- TEST INFRASTRUCTURE.  CPU operator backend with the interface of
+mocopci_amd.ops.HipBackend, built on the C oracle (oracle/pointset.py).  Installed with
+mocopci_amd.ops.set_backend(OracleBackend()) by tests and by bench.py's cpu_baseline leg
+to run the model harness graph on host cores; never used on the product path."""
+import torch
+
+from . import pointset as orc
+
+
+class OracleBackend:
+    name = "oracle-cpu"
+
+    def fps(self, xyz, npoint):
+        return orc.furthest_point_sample(xyz, npoint)
+
+    def knn(self, query, ref, k, mode=0, return_dist=False):
+        return orc.knn(query, ref, k, mode=mode, return_dist=return_dist)
+
+    def knn_cosine(self, qfeat, rfeat, k):
+        return orc.knn_cosine(qfeat, rfeat, k)
+
+    def group_rows(self, points, idx):
+        return orc.group_rows(points, idx.int())
+
+    def interp3_search(self, dense, sparse):
+        idx3 = orc.knn(dense, sparse, 3, mode=0)
+        B, N, _ = dense.shape
+        w3 = torch.empty(B, N, 3, dtype=torch.float32)
+        orc.lib().orc_interp3_weights(orc._f(dense.contiguous()), orc._f(sparse.contiguous()), orc._i(idx3), orc._f(w3), B, N,
+                                      sparse.shape[1])
+        return idx3, w3
+
+    def interp3_apply(self, feat, idx3, w3):
+        B, N, _ = idx3.shape
+        S, C = feat.shape[1], feat.shape[2]
+        out = torch.empty(B, N, C, dtype=torch.float32)
+        orc.lib().orc_interp3_apply(orc._f(feat.contiguous()), orc._i(idx3.contiguous()), orc._f(w3.contiguous()), orc._f(out), B,
+                                    N, S, C)
+        return out
+
+    def interp3(self, dense, sparse, feat):
+        return orc.interp3(dense, sparse, feat)
+
+    def chamfer(self, x, y):
+        return torch.tensor(orc.chamfer(x, y), dtype=torch.float32)
