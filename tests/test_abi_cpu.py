@@ -1,0 +1,42 @@
+"""-m "not gpu": the C-ABI library loads without a GPU and exports every symbol include/mocopci_hip.h
+declares; the ctypes signature table matches the header's argument counts.  No compute calls."""
+import os
+import re
+
+from mocopci_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mocopci_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"(?:int|const char \*)\s*(mcp_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    decl = header_functions()
+    assert len(decl) >= 18
+    lib = _lib.load()
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+        assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
+    assert set(_lib.SIGNATURES) == set(decl)
+
+
+def test_version_and_error_strings():
+    lib = _lib.load()
+    assert lib.mcp_abi_version() == 1
+    assert lib.mcp_error_string(0) == b"ok"
+    assert b"bad argument" in lib.mcp_error_string(10001)
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _lib.load()
+    assert lib.mcp_furthest_point_sampling(0, 0, 0, None, None, None, None) == 10001
+    assert lib.mcp_knn(1, 1, 1, 64, 0, None, None, None, None, None) == 10001

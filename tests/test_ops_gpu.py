@@ -1,0 +1,163 @@
+"""-m gpu: parity of every HIP entry point (called through the C ABI via mocopci_amd.pointnet2_utils /
+mocopci_amd.ops) against the CPU oracle on the same seeded inputs.  Bit-exact for indices and for
+values produced by the shared floating-point canon; property checks at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+import torch
+
+from mocopci_amd import _lib, ops, pointnet2_utils as pu
+from oracle import pointset as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def cloud(seed, b, n, dup=0.05, extent=(40.0, 40.0, 3.0)):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(b, n, 3, generator=g) * 2 - 1) * torch.tensor(extent)
+    nd = int(n * dup)
+    if nd:
+        src = torch.randint(0, n - nd, (nd,), generator=g)
+        x[:, n - nd:] = x[:, src]
+        x = x[:, torch.randperm(n, generator=g)]
+    return x.contiguous()
+
+
+def test_library_loaded_in_process():
+    lib = _lib.load()
+    assert lib.mcp_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 1024, 256), (2, 8192, 2048), (3, 2048, 512), (2, 512, 256), (2, 256, 64),
+                                   (1, 1000, 333), (2, 100, 40), (2, 40, 17), (1, 3, 3), (1, 1024, 2048), (1, 16384, 512),
+                                   (1, 20000, 64)])
+def test_fps_bit_exact(b, n, m):
+    xyz = cloud(100 + n, b, n)
+    want = orc.furthest_point_sample(xyz, m)
+    got = pu.furthest_point_sample(xyz.to(DEV), m)
+    assert got.dtype == torch.int32 and got.shape == (b, m)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_fps_ties_all_equal_points():
+    # every point identical: all distances tie at 0 -> the reference tree picks index 0 forever
+    xyz = torch.ones(1, 777, 3)
+    got = pu.furthest_point_sample(xyz.to(DEV), 9).cpu()
+    assert torch.equal(got, orc.furthest_point_sample(xyz, 9)) and int(got.abs().sum()) == 0
+
+
+def test_fps_prefix_property_full_size():
+    # BASELINE config 5 shape (streaming kernel): FPS(m) is a prefix of FPS(2m); first index is 0; no repeats
+    xyz = cloud(5, 1, 65536, dup=0.0).to(DEV)
+    a = pu.furthest_point_sample(xyz, 64).cpu()
+    b = pu.furthest_point_sample(xyz, 128).cpu()
+    assert torch.equal(a[0], b[0, :64]) and int(a[0, 0]) == 0 and len(set(b[0].tolist())) == 128
+
+
+def test_gather_group_and_grads():
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(2, 19, 500, generator=g)
+    idx = torch.randint(0, 500, (2, 77), generator=g, dtype=torch.int32)
+    assert torch.equal(pu.gather_operation(feats.to(DEV), idx.to(DEV)).cpu(), orc.gather_operation(feats, idx))
+    gidx = torch.randint(0, 500, (2, 60, 9), generator=g, dtype=torch.int32)
+    assert torch.equal(pu.grouping_operation(feats.to(DEV), gidx.to(DEV)).cpu(), orc.grouping_operation(feats, gidx))
+    # backward = scatter-add (atomics: order differs, compare with tolerance)
+    f = feats.to(DEV).requires_grad_(True)
+    out = pu.grouping_operation(f, gidx.to(DEV))
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(DEV))
+    torch.testing.assert_close(f.grad.cpu(), orc.grouping_operation_grad(go, gidx, 500), rtol=1e-5, atol=1e-5)
+    f2 = feats.to(DEV).requires_grad_(True)
+    out = pu.gather_operation(f2, idx.to(DEV))
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(DEV))
+    torch.testing.assert_close(f2.grad.cpu(), orc.gather_operation_grad(go, idx, 500), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("radius,nsample", [(0.5, 16), (1.0, 16), (2.0, 8), (4.0, 8), (1e-4, 4)])
+def test_ball_query_bit_exact(radius, nsample):
+    xyz = cloud(11, 2, 16384, extent=(50.0, 50.0, 4.0))  # config 4 shape
+    new_xyz = xyz[:, :2048].contiguous() + 0.01
+    want = orc.ball_query(radius, nsample, xyz, new_xyz)
+    got = pu.ball_query(radius, nsample, xyz.to(DEV), new_xyz.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    if radius == 1e-4:
+        assert int(want.abs().sum()) == 0  # empty balls stay zero (pre-zeroed idx)
+
+
+@pytest.mark.parametrize("n,m", [(8192, 2048), (1000, 300), (50, 2), (7, 1)])
+def test_three_nn_and_interpolate(n, m):
+    unknown, known = cloud(21, 2, n), cloud(22, 2, m)
+    wd, wi = orc.three_nn(unknown, known)
+    gd, gi_ = pu.three_nn(unknown.to(DEV), known.to(DEV))
+    assert torch.equal(gi_.cpu(), wi)
+    # the kernel's squared distances are bit-exact (inf where m < 3, like the reference's 1e40); the Python
+    # wrapper's torch.sqrt runs on the device and may differ from the host sqrt by an ulp
+    from mocopci_amd import pointnet2_cuda
+    d2 = torch.empty(2, n, 3, device=DEV)
+    i2 = torch.empty(2, n, 3, dtype=torch.int32, device=DEV)
+    pointnet2_cuda.three_nn_wrapper(2, n, m, unknown.to(DEV), known.to(DEV), d2, i2)
+    assert torch.equal(torch.sqrt(d2.cpu()), wd) and torch.equal(i2.cpu(), wi)
+    torch.testing.assert_close(gd.cpu(), wd, rtol=2e-7, atol=0)
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(2, 13, m, generator=g)
+    w = torch.rand(2, n, 3, generator=g)
+    got = pu.three_interpolate(feats.to(DEV), wi.to(DEV), w.to(DEV)).cpu()
+    assert torch.equal(got, orc.three_interpolate(feats, wi, w))
+
+
+@pytest.mark.parametrize("q,n,k,mode", [(8192, 8192, 32, 0), (2048, 8192, 32, 0), (2048, 2048, 16, 0), (2048, 2048, 16, 1),
+                                        (8192, 2048, 3, 0), (512, 256, 32, 0), (256, 64, 32, 0), (300, 1000, 7, 1), (64, 20, 32, 0),
+                                        (1000, 3000, 1, 1), (70, 5000, 16, 0)])
+def test_knn_bit_exact(q, n, k, mode):
+    b = 2
+    query, ref = cloud(31 + q, b, q), cloud(32 + n, b, n)
+    if q == n:
+        ref = query  # self search with exact duplicates: the lexicographic tie rule decides
+    wi, wd = orc.knn(query, ref, k, mode=mode, return_dist=True)
+    gi_, gd = ops.backend().knn(query.to(DEV), ref.to(DEV), k, mode=mode, return_dist=True)
+    assert torch.equal(gi_.cpu(), wi)
+    assert torch.equal(gd.cpu(), wd)
+
+
+def test_knn_full_size_properties():
+    # config 2 / 5 shapes: ascending distances, self is the nearest (distance of a point to itself is the
+    # smallest expansion value up to rounding), indices in range and unique per row
+    for b, n, k in ((8, 8192, 32), (1, 65536, 32)):
+        x = cloud(41, b, n, dup=0.0).to(DEV)
+        q = x[:, :2048].contiguous()
+        idx, dist = ops.backend().knn(q, x, k, mode=1, return_dist=True)
+        assert bool((dist[..., 1:] >= dist[..., :-1]).all())
+        assert torch.equal(idx[..., 0].cpu(), torch.arange(2048, dtype=torch.int32).expand(b, -1))
+        assert int(idx.min()) >= 0 and int(idx.max()) < n
+        s = torch.sort(idx.long(), -1)[0]
+        assert bool((s[..., 1:] != s[..., :-1]).all())
+
+
+@pytest.mark.parametrize("c", [3, 35, 64, 256])
+def test_group_rows(c):
+    g = torch.Generator().manual_seed(c)
+    pts = torch.randn(2, 700, c, generator=g)
+    idx = torch.randint(0, 700, (2, 300, 8), generator=g, dtype=torch.int32)
+    got = ops.backend().group_rows(pts.to(DEV), idx.to(DEV)).cpu()
+    assert torch.equal(got, orc.group_rows(pts, idx))
+
+
+@pytest.mark.parametrize("n,s,c", [(8192, 2048, 3), (2048, 512, 128), (512, 256, 256), (256, 64, 5)])
+def test_interp3_bit_exact(n, s, c):
+    dense, sparse = cloud(51, 2, n), cloud(52, 2, s)
+    feat = torch.randn(2, s, c, generator=torch.Generator().manual_seed(9))
+    want = orc.interp3(dense, sparse, feat)
+    be = ops.backend()
+    got = be.interp3(dense.to(DEV), sparse.to(DEV), feat.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    idx3, w3 = be.interp3_search(dense.to(DEV), sparse.to(DEV))
+    assert torch.equal(be.interp3_apply(feat.to(DEV), idx3, w3).cpu(), want)
+
+
+def test_chamfer_matches_oracle():
+    x, y = cloud(61, 2, 4096), cloud(62, 2, 3000)
+    got = float(ops.backend().chamfer(x.to(DEV), y.to(DEV)))
+    want = orc.chamfer(x, y)
+    assert abs(got - want) <= 1e-6 * abs(want)  # fp32 mean vs double mean
