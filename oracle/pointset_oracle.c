@@ -29,6 +29,10 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+#include <omp.h>
+ORC_API void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+ORC_API int orc_get_threads(void) { return omp_get_max_threads(); }
+
 static inline float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
     /* (a-b)^2 summed, canon order; a is the "second" operand in the .cu text only by name */
     float dx = ax - bx, dy = ay - by, dz = az - bz;
