@@ -113,6 +113,15 @@ int mcp_interp3(int b, int n, int s, int c, const float *dense, const float *spa
 int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, const int *idx3, const float *w3, float *out,
                       mcp_stream_t stream);
 
+/* MultiFrameEstimatier.knn_group + fusion (mocopci.py:798-819) after the two neighbour searches:
+ * p1 (B,N,3) centres, p2 (B,N,3) gathered set, idx (B,N,64) int32 into p2 (32 self-neighbours of p1
+ * followed by 32 neighbours of p1 in p2); per neighbour [d, |d|] -> 4->64->64->128 (1x1 conv + eval
+ * BatchNorm folded into w,b by the caller + ReLU) -> channel max -> softmax over the 64 neighbours ->
+ * weighted sum of neighbour coordinates -> out (B,N,3).  w1 (64,4), w2 (64,64), w3 (128,64) row-major.
+ * nb must be 64 (the reference's fixed k = 32 + 32). */
+int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const float *w1, const float *b1,
+               const float *w2, const float *b2, const float *w3, const float *b3, float *out, mcp_stream_t stream);
+
 /* chamfer_loss (models/utils.py:36-45 -> pytorch3d chamfer_distance defaults): per-point squared
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
@@ -126,6 +135,7 @@ int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *d
 #define MCP_KERNEL_GROUP_ROWS 3
 #define MCP_KERNEL_INTERP3 4
 #define MCP_KERNEL_KNN_COSINE 5
+#define MCP_KERNEL_FUSION 6
 int mcp_prof_enable(int kernel_id); /* 0 disables */
 int mcp_prof_collect(int *launches, float *total_ms);
 

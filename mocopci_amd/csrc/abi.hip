@@ -26,7 +26,7 @@ hipEvent_t take_event() {
         return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 }  // namespace
@@ -35,14 +35,14 @@ void mcp_prof_begin(int kernel_id, hipStream_t s) {
     if (g_kernel != kernel_id) return;  // common case: one relaxed int compare
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t e = take_event();
-    hipEventRecord(e, s);
+    (void)hipEventRecord(e, s);
     g_events.push_back(e);
 }
 void mcp_prof_end(int kernel_id, hipStream_t s) {
     if (g_kernel != kernel_id) return;
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t e = take_event();
-    hipEventRecord(e, s);
+    (void)hipEventRecord(e, s);
     g_events.push_back(e);
 }
 
@@ -59,7 +59,7 @@ MCP_EXPORT int mcp_prof_collect(int *launches, float *total_ms) {
     int n = 0;
     float tot = 0.f;
     for (size_t i = 0; i + 1 < g_events.size(); i += 2) {
-        hipEventSynchronize(g_events[i + 1]);
+        (void)hipEventSynchronize(g_events[i + 1]);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_events[i], g_events[i + 1]) == hipSuccess) {
             tot += ms;

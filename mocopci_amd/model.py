@@ -302,18 +302,22 @@ class MoCoPCI(nn.Module):
         res = torch.sum(attn * (v + pos), dim=2)
         return self.lin(res, prefix + ".fc2") + feats
 
+    def folded_conv_bn(self, conv, bn, eps):
+        """1x1 conv followed by eval-mode BatchNorm as one affine map (cached)."""
+        key = ("fold", conv, bn)
+        P = self._params()
+        if key not in P:
+            scale = P[bn + ".weight"] * torch.rsqrt(P[bn + ".running_var"] + eps)
+            P[key] = ((self.W(conv) * scale[:, None]).contiguous(), ((self.Bv(conv) - P[bn + ".running_mean"]) * scale + P[bn + ".bias"]).contiguous())
+        return P[key]
+
     def fusion(self, p1, p2, k=32):
         """MultiFrameEstimatier.knn_group + fusion (mocopci.py:798-819).  p1, p2 (B,N,3)."""
         be = ops.backend()
         m = "multi_frame_inference.conv."
         idx = torch.cat([be.knn(p1, p1, k), be.knn(p1, p2, k)], dim=-1)            # (B,N,2k) both index p2
-        nb = be.group_rows(p2, idx)                                                # (B,N,2k,3)
-        resi = nb - p1.unsqueeze(2)
-        x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)      # (B,N,2k,4)
-        for ci, bi in ((0, 1), (3, 4), (6, 7)):
-            x = F.relu(self.bn_eval(self.lin(x, m + str(ci)), m + str(bi), 1e-3))
-        w = F.softmax(x.max(dim=-1)[0], dim=-1)                                    # (B,N,2k)
-        return torch.sum(w.unsqueeze(-1) * nb, dim=2)                              # (B,N,3)
+        wb = [t for ci, bi in ((0, 1), (3, 4), (6, 7)) for t in self.folded_conv_bn(m + str(ci), m + str(bi), 1e-3)]
+        return be.fusion_mlp(p1, p2.contiguous(), idx, *wb)
 
     # ---- decoder ------------------------------------------------------------------------
     def run_decoder(self, pcs, feats, B):

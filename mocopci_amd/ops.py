@@ -99,6 +99,14 @@ class HipBackend:
               _lib.iptr(idx3), _lib.fptr(w3))
         return out
 
+    def fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
+        """fusion after the neighbour searches (mocopci.py:803-819), BN folded into (w,b): -> (B,N,3)."""
+        B, N, _ = p1.shape
+        out = torch.empty((B, N, 3), dtype=torch.float32, device=p1.device)
+        _call("mcp_fusion", p1, B, N, idx.shape[-1], _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(idx), _lib.fptr(w1), _lib.fptr(b1),
+              _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(w3), _lib.fptr(b3), _lib.fptr(out))
+        return out
+
     def chamfer(self, x, y):
         """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor."""
         B, N, _ = x.shape
@@ -124,7 +132,7 @@ def set_backend(b):
 
 
 # ---- instrumentation passthrough (bench.py) ----
-KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4}
+KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "fusion": 6}
 
 
 def prof_enable(kernel_name):

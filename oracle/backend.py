@@ -41,5 +41,15 @@ class OracleBackend:
     def interp3(self, dense, sparse, feat):
         return orc.interp3(dense, sparse, feat)
 
+    def fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
+        """Unfused restatement of mocopci.py:803-819 with BN already folded into (w,b)."""
+        nb = orc.group_rows(p2, idx.int())
+        resi = nb - p1.unsqueeze(2)
+        x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)
+        for w, b in ((w1, b1), (w2, b2), (w3, b3)):
+            x = torch.relu(torch.nn.functional.linear(x, w, b))
+        wgt = torch.softmax(x.max(dim=-1)[0], dim=-1)
+        return torch.sum(wgt.unsqueeze(-1) * nb, dim=2)
+
     def chamfer(self, x, y):
         return torch.tensor(orc.chamfer(x, y), dtype=torch.float32)

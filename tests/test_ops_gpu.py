@@ -161,3 +161,20 @@ def test_chamfer_matches_oracle():
     got = float(ops.backend().chamfer(x.to(DEV), y.to(DEV)))
     want = orc.chamfer(x, y)
     assert abs(got - want) <= 1e-6 * abs(want)  # fp32 mean vs double mean
+
+
+def test_fusion_mlp_matches_unfused_oracle():
+    """mcp_fusion (fp32 MFMA chain) vs the unfused torch-CPU restatement: fp32 tolerance 1e-5 relative
+    on coordinates of magnitude ~40 (sum order differs, arithmetic is exact fp32 on both sides)."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(77)
+    B, N = 2, 1500
+    p1 = cloud(71, B, N)
+    p2 = (p1 + 0.2 * torch.randn(B, N, 3, generator=g)).contiguous()
+    idx = torch.cat([orc.knn(p1, p1, 32), orc.knn(p1, p2, 32)], -1)
+    ws = []
+    for co, ci in ((64, 4), (64, 64), (128, 64)):
+        ws += [torch.randn(co, ci, generator=g) / ci ** 0.5, 0.1 * torch.randn(co, generator=g)]
+    want = OracleBackend().fusion_mlp(p1, p2, idx, *ws)
+    got = ops.backend().fusion_mlp(p1.to(DEV), p2.to(DEV), idx.to(DEV), *[w.to(DEV) for w in ws]).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-4)
