@@ -122,6 +122,16 @@ int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, const int *
 int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const float *w1, const float *b1,
                const float *w2, const float *b2, const float *w3, const float *b3, float *out, mcp_stream_t stream);
 
+/* Cost-volume cross() after its neighbour searches (pointconv_util.py:750-781, :894-922, :1126-1161):
+ * xyz1 (B,N1,3), xyz2 (B,N2,3), points1 (B,N1,D), points2 (B,N2,D) channel-last (16-byte aligned),
+ * idx (B,N1,32) int32 into set 2 (16 feature-cosine + 16 xyz neighbours), wpos (D,3), bpos (D) = the
+ * Conv2d 3->D on xyz2[idx]-xyz1, wmlp (D,D), bmlp (D) = the single Conv2d D->D of the mlp list
+ * (every layer MoCoPCI builds has exactly one) -> out (B,N1,D) = max over the 32 neighbours of
+ * LeakyReLU(wmlp . LeakyReLU(points2[idx] + points1 + pos) + bmlp).  D in {64,128}, k must be 32. */
+int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
+                     const float *points2, const int *idx, const float *wpos, const float *bpos, const float *wmlp,
+                     const float *bmlp, float *out, mcp_stream_t stream);
+
 /* chamfer_loss (models/utils.py:36-45 -> pytorch3d chamfer_distance defaults): per-point squared
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
@@ -136,6 +146,7 @@ int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *d
 #define MCP_KERNEL_INTERP3 4
 #define MCP_KERNEL_KNN_COSINE 5
 #define MCP_KERNEL_FUSION 6
+#define MCP_KERNEL_CROSS 7
 int mcp_prof_enable(int kernel_id); /* 0 disables */
 int mcp_prof_collect(int *launches, float *total_ms);
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mcp_interp3": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_fusion": [_i, _i, _i] + [_p] * 11,
+    "mcp_cross_volume": [_i] * 5 + [_p] * 11,
     "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_prof_enable": [_i],
     "mcp_prof_collect": [_p, _p],

@@ -1,0 +1,174 @@
+// cross.hip -- fused PointPWC-style cost volume ("cross") for gfx950.
+//
+// Reference: CrossLayerLightFeatCosine.cross (pointconv_util.py:750-781),
+// BidirectionalLayerFeatCosine.cross (:894-922), FlowEmbeddingLayer.forward (:1126-1161),
+// after their two neighbour searches:
+//     x0 = LeakyReLU_0.1( points2[idx] + points1 + Conv2d_{3->D}(xyz2[idx] - xyz1) )     (B,D,32,N1)
+//     x1 = LeakyReLU_0.1( Conv2d_{D->D}(x0) )
+//     out = max over the 32 neighbours
+// The reference does this with 4 K5 gathers (each with two permute copies), ~8 elementwise /
+// conv launches and a max-pool, materialising (B,D,32,N1) three times.  Here one wave owns one
+// point; its 32 neighbours sit on the MFMA column (lane & 31):
+//   * the positional term is an MFMA with K=4 ([dx,dy,dz,1] x [Wpos|bpos]) whose accumulator is
+//     initialised with points1 (broadcast over neighbours);
+//   * gathered rows of points2 are loaded straight INTO the accumulator layout: register r of
+//     lane-half h is channel 32t + (r&3) + 8(r>>2) + 4h, i.e. four float4 loads per 32-channel tile;
+//   * the D->D layer runs on v_mfma_f32_32x32x2_f32 with x0's accumulator tiles as its B operand
+//     (weights pre-permuted in LDS, as in fusion.hip), bias as the initial accumulator;
+//   * the max over neighbours is a DPP row reduction + one cross-row shuffle per register.
+// HBM/L2 traffic is the compulsory gather (32 rows of D floats per point) + D floats out.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int WAVES = 4;
+constexpr int KNB = 32;
+constexpr float SLOPE = 0.1f;  // pointconv_util.py:10
+
+__device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * SLOPE; }
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __uint_as_float(mcp_dpp<CTRL>(__float_as_uint(v)));
+}
+// max over the 32 lanes that share lane>>5
+__device__ __forceinline__ float half_max(float v) {
+    v = fmaxf(v, dppf<0xB1>(v));
+    v = fmaxf(v, dppf<0x4E>(v));
+    v = fmaxf(v, dppf<0x141>(v));
+    v = fmaxf(v, dppf<0x140>(v));
+    return fmaxf(v, __shfl_xor(v, 16));
+}
+
+template <int D>
+struct CrossLds {
+    static constexpr int T = D / 32;
+    static constexpr int W_FLOATS = T * (T * 16 / 4) * 64 * 4;  // [t_out][kquad][lane][4]  = D*D
+    static constexpr int POS_FLOATS = T * 2 * 64;               // [t][kstep][lane]
+    static constexpr int B_FLOATS = T * 2 * 16;                 // [t][half][r]
+    static constexpr int OFF_W = 0, OFF_POS = W_FLOATS, OFF_B = OFF_POS + POS_FLOATS;
+    static constexpr int FLOATS = OFF_B + B_FLOATS;
+};
+
+template <int D>
+__global__ __launch_bounds__(64 * WAVES) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
+                                                           const float *__restrict__ xyz2, const float *__restrict__ points1,
+                                                           const float *__restrict__ points2, const int *__restrict__ idx,
+                                                           const float *__restrict__ wpos, const float *__restrict__ bpos,
+                                                           const float *__restrict__ wmlp, const float *__restrict__ bmlp,
+                                                           float *__restrict__ out) {
+    using L = CrossLds<D>;
+    constexpr int T = L::T, KQ = T * 4;  // k-quads per output tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < L::W_FLOATS; e += 64 * WAVES) {
+        const int j = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % KQ, t = (e >> 8) / KQ;
+        const int s = 4 * q + j, tin = s >> 4, r = s & 15;
+        lds[L::OFF_W + e] = wmlp[(32 * t + (lane & 31)) * D + 32 * tin + chan_of(r, lane >> 5)];
+    }
+    for (int e = tid; e < L::POS_FLOATS; e += 64 * WAVES) {  // [t][s][lane]: columns (dx,dy | dz,1)
+        const int lane = e & 63, s = (e >> 6) & 1, t = e >> 7;
+        const int row = 32 * t + (lane & 31), c = 2 * s + (lane >> 5);
+        lds[L::OFF_POS + e] = c < 3 ? wpos[row * 3 + c] : bpos[row];
+    }
+    for (int e = tid; e < L::B_FLOATS; e += 64 * WAVES) {
+        const int r = e & 15, h = (e >> 4) & 1, t = e >> 5;
+        lds[L::OFF_B + e] = bmlp[32 * t + chan_of(r, h)];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    const float4 *wq = reinterpret_cast<const float4 *>(lds + L::OFF_W);
+
+    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+        const long long bb = p / n1;
+        const int id = idx[p * KNB + col];
+        const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
+        const float dx = q2[0] - xyz1[p * 3 + 0], dy = q2[1] - xyz1[p * 3 + 1], dz = q2[2] - xyz1[p * 3 + 2];
+        const float in0 = h ? dy : dx, in1 = h ? 1.0f : dz;
+        const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)bb * n2 + id) * D);
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + p * D);
+
+        f32x16 x0[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x16 acc;
+            float4 g2[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // channels 32t + 8g + 4h .. +3  ->  registers 4g .. 4g+3
+                const float4 a = row1[(32 * t + 8 * g + 4 * h) >> 2];
+                g2[g] = row2[(32 * t + 8 * g + 4 * h) >> 2];
+                acc[4 * g + 0] = a.x; acc[4 * g + 1] = a.y; acc[4 * g + 2] = a.z; acc[4 * g + 3] = a.w;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L::OFF_POS + (t * 2 + 0) * 64 + lane], in0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L::OFF_POS + (t * 2 + 1) * 64 + lane], in1, acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[4 * g + 0] = leaky(acc[4 * g + 0] + g2[g].x);
+                acc[4 * g + 1] = leaky(acc[4 * g + 1] + g2[g].y);
+                acc[4 * g + 2] = leaky(acc[4 * g + 2] + g2[g].z);
+                acc[4 * g + 3] = leaky(acc[4 * g + 3] + g2[g].w);
+            }
+            x0[t] = acc;
+        }
+        float4 *orow = reinterpret_cast<float4 *>(out + p * D);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = lds[L::OFF_B + (t * 2 + h) * 16 + r];
+#pragma unroll
+            for (int q4 = 0; q4 < KQ; ++q4) {
+                const float4 w = wq[(t * KQ + q4) * 64 + lane];
+                const int tin = q4 >> 2, r0 = (q4 & 3) * 4;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x0[tin][r0 + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x0[tin][r0 + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x0[tin][r0 + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x0[tin][r0 + 3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = half_max(leaky(acc[r]));  // leaky is monotone: max commutes
+            if (col == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    orow[(32 * t + 8 * g + 4 * h) >> 2] = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_cross(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
+                 const int *idx, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, float *out,
+                 hipStream_t s) {
+    const size_t lds = CrossLds<D>::FLOATS * sizeof(float);
+    auto kern = cross_kernel<D>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)min((total + WAVES - 1) / WAVES, (long long)(lds > 40 * 1024 ? 512 : 1024));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp,
+                       bmlp, out);
+    return mcp_launch_status();
+}
+
+}  // namespace
+
+MCP_EXPORT int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
+                                const float *points2, const int *idx, const float *wpos, const float *bpos, const float *wmlp,
+                                const float *bmlp, float *out, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && wpos && bpos && wmlp && bmlp && out);
+    if (k != KNB || (d != 64 && d != 128)) return MCP_ERR_UNSUPPORTED;
+    if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)out)) & 15) return MCP_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)b * n1;
+    mcp_prof_begin(MCP_KERNEL_CROSS, s);
+    const int rc = d == 64 ? launch_cross<64>(total, n1, n2, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, out, s)
+                           : launch_cross<128>(total, n1, n2, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, out, s);
+    mcp_prof_end(MCP_KERNEL_CROSS, s);
+    return rc;
+}

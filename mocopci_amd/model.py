@@ -163,6 +163,11 @@ class MoCoPCI(nn.Module):
         else:
             idx_p = be.knn(xyz1, xyz2, 16)
         idx = torch.cat([idx_c, idx_p], dim=-1)                           # (B,N1,32)
+        D = points1.shape[-1]
+        if len(mlp) == 1 and D in (64, 128) and points2.shape[-1] == D:
+            conv = mlp[0] + ".composed_module.0"
+            return be.cross_volume(xyz1, xyz2, points1.contiguous(), points2.contiguous(), idx, self.W(pos), self.Bv(pos),
+                                   self.W(conv), self.Bv(conv))
         direction = be.group_rows(xyz2, idx) - xyz1.unsqueeze(2)          # (B,N1,32,3)
         g2 = be.group_rows(points2, idx)                                  # (B,N1,32,D)
         x = leaky((g2 + points1.unsqueeze(2)) + self.lin(direction, pos))

@@ -107,6 +107,15 @@ class HipBackend:
               _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(w3), _lib.fptr(b3), _lib.fptr(out))
         return out
 
+    def cross_volume(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp):
+        """cross() after its neighbour searches (pointconv_util.py:750-781): -> (B,N1,D); D in {64,128}."""
+        B, N1, D = points1.shape
+        N2 = points2.shape[1]
+        out = torch.empty((B, N1, D), dtype=torch.float32, device=points1.device)
+        _call("mcp_cross_volume", points1, B, N1, N2, D, idx.shape[-1], _lib.fptr(xyz1), _lib.fptr(xyz2), _lib.fptr(points1),
+              _lib.fptr(points2), _lib.iptr(idx), _lib.fptr(wpos), _lib.fptr(bpos), _lib.fptr(wmlp), _lib.fptr(bmlp), _lib.fptr(out))
+        return out
+
     def chamfer(self, x, y):
         """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor."""
         B, N, _ = x.shape
@@ -132,7 +141,7 @@ def set_backend(b):
 
 
 # ---- instrumentation passthrough (bench.py) ----
-KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "fusion": 6}
+KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "fusion": 6, "cross": 7}
 
 
 def prof_enable(kernel_name):

@@ -51,5 +51,14 @@ class OracleBackend:
         wgt = torch.softmax(x.max(dim=-1)[0], dim=-1)
         return torch.sum(wgt.unsqueeze(-1) * nb, dim=2)
 
+    def cross_volume(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp):
+        """Unfused restatement of pointconv_util.py:765-781 (one mlp layer)."""
+        F = torch.nn.functional
+        direction = orc.group_rows(xyz2, idx.int()) - xyz1.unsqueeze(2)
+        g2 = orc.group_rows(points2, idx.int())
+        x = F.leaky_relu((g2 + points1.unsqueeze(2)) + F.linear(direction, wpos, bpos), 0.1)
+        x = F.leaky_relu(F.linear(x, wmlp, bmlp), 0.1)
+        return x.max(dim=2)[0]
+
     def chamfer(self, x, y):
         return torch.tensor(orc.chamfer(x, y), dtype=torch.float32)

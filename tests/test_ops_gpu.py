@@ -178,3 +178,18 @@ def test_fusion_mlp_matches_unfused_oracle():
     want = OracleBackend().fusion_mlp(p1, p2, idx, *ws)
     got = ops.backend().fusion_mlp(p1.to(DEV), p2.to(DEV), idx.to(DEV), *[w.to(DEV) for w in ws]).cpu()
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("d,n1,n2", [(64, 2048, 2048), (128, 512, 512), (64, 300, 777)])
+def test_cross_volume_matches_unfused_oracle(d, n1, n2):
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(d + n1)
+    B = 2
+    xyz1, xyz2 = cloud(81, B, n1), cloud(82, B, n2)
+    p1, p2 = torch.randn(B, n1, d, generator=g), torch.randn(B, n2, d, generator=g)
+    idx = torch.randint(0, n2, (B, n1, 32), generator=g, dtype=torch.int32)
+    wpos, bpos = torch.randn(d, 3, generator=g) * 0.3, torch.randn(d, generator=g) * 0.1
+    wmlp, bmlp = torch.randn(d, d, generator=g) / d ** 0.5, torch.randn(d, generator=g) * 0.1
+    want = OracleBackend().cross_volume(xyz1, xyz2, p1, p2, idx, wpos, bpos, wmlp, bmlp)
+    got = ops.backend().cross_volume(*[t.to(DEV) for t in (xyz1, xyz2, p1, p2, idx, wpos, bpos, wmlp, bmlp)]).cpu()
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
