@@ -99,6 +99,13 @@ int mcp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
 int mcp_knn(int b, int q, int n, int k, int dist_form, const float *query, const float *ref, int *idx, float *dist,
             mcp_stream_t stream);
 
+/* knn_point_cosine(nsample, xyz, new_xyz) (pointconv_util.py:111-153) on channel-last features:
+ * qfeat (B,Q,C), rfeat (B,N,C) -> idx (B,Q,K) (and dist if non-NULL): the K smallest of
+ * d = 1 - <q^,r^>, x^ = x / sqrt(sum x^2 + 1e-8), under the order (d, index), ascending.
+ * C in {64,128,256}, 1 <= K <= 16.  workspace: B*(Q+N)*C floats (normalised copies), caller-owned. */
+int mcp_knn_cosine(int b, int q, int n, int c, int k, const float *qfeat, const float *rfeat, int *idx, float *dist,
+                   float *workspace, mcp_stream_t stream);
+
 /* index_points_group / index_points_gather (mocopci.py:1190-1215) without the permute copies:
  * points (B,N,C) channel-last, idx (B,T) -> out (B,T,C) (T = S*K or S), whole C*4-byte rows. */
 int mcp_group_rows(int b, int n, int c, int t, const float *points, const int *idx, float *out, mcp_stream_t stream);

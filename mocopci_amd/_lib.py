@@ -27,6 +27,7 @@ SIGNATURES = {
     "mcp_three_interpolate": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_three_interpolate_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_knn": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_knn_cosine": [_i] * 5 + [_p] * 6,
     "mcp_group_rows": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_interp3": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],

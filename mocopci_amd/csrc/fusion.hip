@@ -22,7 +22,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int C1 = 64, C2 = 64, C3 = 128, NB = 64;  // mocopci.py:749-755, fusion k = 32 + 32
+constexpr int C1 = 64, C2 = 64, NB = 64;  // layer widths 4 -> 64 -> 64 -> 128  // mocopci.py:749-755, fusion k = 32 + 32
 constexpr int WAVES = 4;
 
 // LDS image (floats):

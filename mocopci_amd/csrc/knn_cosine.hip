@@ -1,0 +1,223 @@
+// knn_cosine.hip -- feature-space cosine KNN on fp32 MFMA for gfx950.
+//
+// Replaces cosine_distance + torch.topk (pointconv_util.py:111-153): the reference normalises both
+// feature sets, materialises 1 - Q^ . R^T as a (B,Q,N) matrix with bmm and takes the 16 smallest per
+// row (39 calls per forward).  Here the correlation tile never leaves registers:
+//   * rows are normalised once (x / sqrt(sum x^2 + 1e-8)) into a caller-provided workspace;
+//   * a wave owns 32 queries: they sit on the MFMA column (lane & 31) and their features are the
+//     B operand, resident in VGPRs (C/2 registers per lane);
+//   * reference features stream through a double-buffered LDS tile of 32 rows (row stride C+1 floats:
+//     the per-k-step A-operand read is bank-conflict-free) shared by the 4 waves of a workgroup;
+//   * per tile, C/2 v_mfma_f32_32x32x2_f32 accumulate the 32x32 correlation block as an exact fp32,
+//     k-ordered fma chain (the oracle's definition); lane (query j, half h) then holds 16 of the 32
+//     reference rows, filters them against its running 16-th best into an LDS queue and merges with
+//     the register bitonic network shared with knn.hip; the two lane halves of a query are merged at
+//     the end.
+// Result: the K smallest of d = 1 - dot under the lexicographic order (d, index), ascending.
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr u64 KEY_INF = ~0ull;
+constexpr int K = 16, QS = 16, CHK = 4, RT = 32, WAVES = 4;
+
+__device__ __forceinline__ void ce_asc(u64 &a, u64 &b) {
+    const bool sw = b < a;
+    const u64 lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+__device__ __forceinline__ void ce_dir(u64 &a, u64 &b, bool up) {
+    const bool sw = up ? (b < a) : (a < b);
+    const u64 x = sw ? b : a, y = sw ? a : b;
+    a = x;
+    b = y;
+}
+template <int N>
+__device__ __forceinline__ void bitonic_sort(u64 (&v)[N]) {
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ j;
+                if (l > i) ce_dir(v[i], v[l], (i & k) == 0);
+            }
+}
+template <int N>
+__device__ __forceinline__ void merge_equal(u64 (&a)[N], const u64 (&q)[N]) {  // both ascending -> a = N smallest
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const u64 o = q[N - 1 - i];
+        a[i] = o < a[i] ? o : a[i];
+    }
+#pragma unroll
+    for (int j = N >> 1; j > 0; j >>= 1)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int l = i ^ j;
+            if (l > i) ce_asc(a[i], a[l]);
+        }
+}
+__device__ __forceinline__ float tau_of(u64 kth) {
+    const uint32_t hi = (uint32_t)(kth >> 32);
+    return hi == 0xFFFFFFFFu ? INFINITY : mcp_unord(hi);
+}
+__device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// x / sqrt(sum(x^2) + 1e-8): sequential sum of rounded squares (oracle canon), one thread per row
+__global__ __launch_bounds__(256) void normalize_rows_kernel(long long rows, int c, const float *__restrict__ x, float *__restrict__ y) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float *xr = x + r * c;
+    float s = 0.f;
+    for (int j = 0; j < c; ++j) s = s + xr[j] * xr[j];
+    const float den = sqrtf(s + 1e-8f);
+    float *yr = y + r * c;
+    for (int j = 0; j < c; ++j) yr[j] = xr[j] / den;
+}
+
+template <int C>
+__global__ __launch_bounds__(64 * WAVES) void knn_cosine_kernel(int q, int n, int kout, const float *__restrict__ nq,
+                                                                const float *__restrict__ nr, int *__restrict__ idx,
+                                                                float *__restrict__ dist) {
+    constexpr int S = C + 1;                     // padded LDS row stride (floats)
+    constexpr int PER_THREAD = RT * C / (64 * WAVES);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *tiles = smem;                         // [2][RT * S]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    uint2(*queue)[64] = reinterpret_cast<uint2(*)[64]>(smem + 2 * RT * S) + (size_t)wave * QS;
+
+    const int b = blockIdx.y;
+    const int qi = blockIdx.x * (32 * WAVES) + wave * 32 + col;
+    const bool live = qi < q;
+    const float *qrow = nq + ((size_t)b * q + (live ? qi : 0)) * C;
+    float bq[C / 2];
+#pragma unroll
+    for (int s = 0; s < C / 2; ++s) bq[s] = qrow[2 * s + h];
+    nr += (size_t)b * n * C;
+
+    u64 a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = KEY_INF;
+    float tau = INFINITY;
+    int cnt = 0;
+    auto flush = [&]() {
+        u64 qk[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const uint2 e = queue[s][lane];
+            qk[s] = s < cnt ? (((u64)mcp_ord(__uint_as_float(e.x)) << 32) | e.y) : KEY_INF;
+        }
+        bitonic_sort<QS>(qk);
+        merge_equal<K>(a, qk);
+        tau = tau_of(a[K - 1]);
+        cnt = 0;
+    };
+
+    const int ntiles = (n + RT - 1) / RT;
+    float pre[PER_THREAD];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int e = tid + u * 64 * WAVES, row = e / C, cc = e % C;
+            const int gr = t * RT + row;
+            pre[u] = gr < n ? nr[(size_t)gr * C + cc] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int e = tid + u * 64 * WAVES, row = e / C, cc = e % C;
+            tiles[buf * RT * S + row * S + cc] = pre[u];
+        }
+    };
+    fetch(0);
+    stash(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) fetch(t + 1);
+        __syncthreads();
+        const float *ta = tiles + cur * RT * S + col * S + h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < C / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[2 * s], bq[s], acc, 0, 0, 0);
+        const int base = t * RT;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += CHK) {
+#pragma unroll
+            for (int r = r0; r < r0 + CHK; ++r) {
+                const int ri = base + chan_of(r, h);
+                const float d = 1.0f - acc[r];
+                if (ri < n && d < tau) {
+                    queue[cnt][lane] = make_uint2(__float_as_uint(d), (uint32_t)ri);
+                    ++cnt;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(cnt > QS - CHK)) flush();
+        }
+        if (t + 1 < ntiles) stash(cur ^ 1);
+    }
+    flush();
+    // merge the two lane halves of each query
+    u64 o[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t lo = __shfl_xor((uint32_t)a[j], 32), hi = __shfl_xor((uint32_t)(a[j] >> 32), 32);
+        o[j] = ((u64)hi << 32) | lo;
+    }
+    merge_equal<K>(a, o);
+    if (!live || h) return;
+    int *oi = idx + ((size_t)b * q + qi) * kout;
+    float *od = dist ? dist + ((size_t)b * q + qi) * kout : nullptr;
+    u64 last = a[0];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < kout) {
+            const u64 kk = a[j] == KEY_INF ? last : a[j];
+            last = kk;
+            oi[j] = kk == KEY_INF ? 0 : (int)(uint32_t)kk;
+            if (od) od[j] = kk == KEY_INF ? 0.f : mcp_unord((uint32_t)(kk >> 32));
+        }
+    }
+}
+
+template <int C>
+int launch_cosine(int b, int q, int n, int k, const float *nq, const float *nr, int *idx, float *dist, hipStream_t s) {
+    const size_t lds = (size_t)2 * RT * (C + 1) * sizeof(float) + (size_t)WAVES * QS * 64 * sizeof(uint2);
+    auto kern = knn_cosine_kernel<C>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 32 * WAVES), b), dim3(64 * WAVES), lds, s, q, n, k, nq, nr, idx, dist);
+    return mcp_launch_status();
+}
+
+}  // namespace
+
+MCP_EXPORT int mcp_knn_cosine(int b, int q, int n, int c, int k, const float *qfeat, const float *rfeat, int *idx, float *dist,
+                              float *workspace, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && q > 0 && n > 0 && c > 0 && k > 0 && qfeat && rfeat && idx && workspace);
+    if (k > K || (c != 64 && c != 128 && c != 256)) return MCP_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float *nq = workspace, *nr = workspace + (size_t)b * q * c;
+    mcp_prof_begin(MCP_KERNEL_KNN_COSINE, s);
+    const long long rq = (long long)b * q, rr = (long long)b * n;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((rq + 255) / 256)), dim3(256), 0, s, rq, c, qfeat, nq);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, s, rr, c, rfeat, nr);
+    int rc = mcp_launch_status();
+    if (rc == MCP_OK) {
+        rc = c == 64    ? launch_cosine<64>(b, q, n, k, nq, nr, idx, dist, s)
+             : c == 128 ? launch_cosine<128>(b, q, n, k, nq, nr, idx, dist, s)
+                        : launch_cosine<256>(b, q, n, k, nq, nr, idx, dist, s);
+    }
+    mcp_prof_end(MCP_KERNEL_KNN_COSINE, s);
+    return rc;
+}

@@ -49,14 +49,17 @@ class HipBackend:
               _lib.fptr(dist) if return_dist else None)
         return (idx, dist) if return_dist else idx
 
-    def knn_cosine(self, qfeat, rfeat, k):
-        """knn_point_cosine(k, rfeat, qfeat) (pointconv_util.py:111-153) on channel-last features.
-        Interim: dense contraction through torch (rocBLAS) + topk; the sets are small here
-        (N <= 2048).  See DESIGN.md for the MFMA kernel that replaces it."""
-        qn = qfeat / torch.sqrt(torch.sum(qfeat ** 2, -1, keepdim=True) + 1e-8)
-        rn = rfeat / torch.sqrt(torch.sum(rfeat ** 2, -1, keepdim=True) + 1e-8)
-        dist = 1.0 - torch.bmm(qn, rn.transpose(1, 2))
-        return torch.topk(dist, k, dim=-1, largest=False, sorted=False)[1].int()
+    def knn_cosine(self, qfeat, rfeat, k, return_dist=False):
+        """knn_point_cosine(k, rfeat, qfeat) (pointconv_util.py:111-153) on channel-last features:
+        (B,Q,C),(B,N,C) -> (B,Q,k) int32, ascending by (1 - cosine, index).  MFMA kernel, C in {64,128,256}."""
+        B, Q, C = qfeat.shape
+        N = rfeat.shape[1]
+        idx = torch.empty((B, Q, k), dtype=torch.int32, device=qfeat.device)
+        dist = torch.empty((B, Q, k), dtype=torch.float32, device=qfeat.device) if return_dist else None
+        ws = torch.empty((B * (Q + N) * C,), dtype=torch.float32, device=qfeat.device)
+        _call("mcp_knn_cosine", qfeat, B, Q, N, C, k, _lib.fptr(qfeat), _lib.fptr(rfeat), _lib.iptr(idx),
+              _lib.fptr(dist) if return_dist else None, _lib.fptr(ws))
+        return (idx, dist) if return_dist else idx
 
     def group_rows(self, points, idx):
         """index_points_group / index_points_gather (mocopci.py:1190-1215): points (B,N,C),
@@ -141,7 +144,7 @@ def set_backend(b):
 
 
 # ---- instrumentation passthrough (bench.py) ----
-KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "fusion": 6, "cross": 7}
+KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7}
 
 
 def prof_enable(kernel_name):

@@ -16,8 +16,8 @@ class OracleBackend:
     def knn(self, query, ref, k, mode=0, return_dist=False):
         return orc.knn(query, ref, k, mode=mode, return_dist=return_dist)
 
-    def knn_cosine(self, qfeat, rfeat, k):
-        return orc.knn_cosine(qfeat, rfeat, k)
+    def knn_cosine(self, qfeat, rfeat, k, return_dist=False):
+        return orc.knn_cosine(qfeat, rfeat, k, return_dist=return_dist)
 
     def group_rows(self, points, idx):
         return orc.group_rows(points, idx.int())

@@ -193,3 +193,16 @@ def test_cross_volume_matches_unfused_oracle(d, n1, n2):
     want = OracleBackend().cross_volume(xyz1, xyz2, p1, p2, idx, wpos, bpos, wmlp, bmlp)
     got = ops.backend().cross_volume(*[t.to(DEV) for t in (xyz1, xyz2, p1, p2, idx, wpos, bpos, wmlp, bmlp)]).cpu()
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("q,n,c,k", [(2048, 2048, 64, 16), (512, 512, 128, 16), (256, 256, 256, 16), (100, 333, 64, 5),
+                                     (130, 20, 128, 16)])
+def test_knn_cosine_bit_exact(q, n, c, k):
+    g = torch.Generator().manual_seed(c + q)
+    qf, rf = torch.randn(2, q, c, generator=g), torch.randn(2, n, c, generator=g)
+    if q == n:
+        rf[:, 7] = rf[:, 3]  # duplicated reference rows: exact ties
+    wi, wd = orc.knn_cosine(qf, rf, k, return_dist=True)
+    gi_, gd = ops.backend().knn_cosine(qf.to(DEV), rf.to(DEV), k, return_dist=True)
+    assert torch.equal(gi_.cpu(), wi)
+    assert torch.equal(gd.cpu(), wd)
