@@ -139,6 +139,15 @@ int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, con
                      const float *points2, const int *idx, const float *wpos, const float *bpos, const float *wmlp,
                      const float *bmlp, float *out, mcp_stream_t stream);
 
+/* PointConv / PointConvD up to the final Linear (mocopci.py:1218-1266, :1289-1300, :1330-1335):
+ * s_xyz (B,N,3), new_xyz (B,S,3) centres, s_points (B,N,D) channel-last, idx (B,S,32) int32 into the
+ * N source points; WeightNet Conv2d 3->8->8->8 + ReLU as w0 (8,3), w1 (8,8), w2 (8,8) and biases.
+ * out (B,S,(3+D)*8), 16-byte aligned: out[b,s,c*8+m] = sum_k [dxyz|feat][k][c] * weightnet(dxyz[k])[m],
+ * i.e. the tensor the reference feeds to self.linear.  k must be 32. */
+int mcp_pointconv_agg(int b, int n, int s, int d, int k, const float *s_xyz, const float *new_xyz, const float *s_points,
+                      const int *idx, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
+                      const float *b2, float *out, mcp_stream_t stream);
+
 /* chamfer_loss (models/utils.py:36-45 -> pytorch3d chamfer_distance defaults): per-point squared
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
@@ -154,6 +163,7 @@ int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *d
 #define MCP_KERNEL_KNN_COSINE 5
 #define MCP_KERNEL_FUSION 6
 #define MCP_KERNEL_CROSS 7
+#define MCP_KERNEL_POINTCONV 8
 int mcp_prof_enable(int kernel_id); /* 0 disables */
 int mcp_prof_collect(int *launches, float *total_ms);
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_fusion": [_i, _i, _i] + [_p] * 11,
     "mcp_cross_volume": [_i] * 5 + [_p] * 11,
+    "mcp_pointconv_agg": [_i] * 5 + [_p] * 12,
     "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_prof_enable": [_i],
     "mcp_prof_collect": [_p, _p],

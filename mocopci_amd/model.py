@@ -117,14 +117,9 @@ class MoCoPCI(nn.Module):
         be = ops.backend()
         B, S, _ = new_xyz.shape
         idx = be.knn(new_xyz, s_xyz, nsample)
-        g_xyz = be.group_rows(s_xyz, idx) - new_xyz.unsqueeze(2)          # (B,S,K,3)
-        g_pts = be.group_rows(s_points, idx)                              # (B,S,K,D)
-        new_points = torch.cat([g_xyz, g_pts], dim=-1)                    # (B,S,K,3+D)
-        w = g_xyz
-        for i in range(3):
-            w = F.relu(self.lin(w, f"{prefix}.weightnet.mlp_convs.{i}"))  # (B,S,K,8)
-        agg = torch.matmul(new_points.transpose(2, 3), w)                 # (B,S,3+D,8)
-        return leaky(self.lin(agg.reshape(B, S, -1), prefix + ".linear"))
+        wn = [t for i in range(3) for t in (self.W(f"{prefix}.weightnet.mlp_convs.{i}"), self.Bv(f"{prefix}.weightnet.mlp_convs.{i}"))]
+        agg = be.pointconv_agg(s_xyz, new_xyz, s_points.contiguous(), idx, *wn)      # (B,S,(3+D)*8)
+        return leaky(self.lin(agg, prefix + ".linear"))
 
     def pointconv_d(self, prefix, npoint, xyz, points):
         be = ops.backend()

@@ -119,6 +119,15 @@ class HipBackend:
               _lib.fptr(points2), _lib.iptr(idx), _lib.fptr(wpos), _lib.fptr(bpos), _lib.fptr(wmlp), _lib.fptr(bmlp), _lib.fptr(out))
         return out
 
+    def pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
+        """PointConv grouping + WeightNet + aggregation (mocopci.py:1330-1335): -> (B,S,(3+D)*8)."""
+        B, N, D = s_points.shape
+        S = new_xyz.shape[1]
+        out = torch.empty((B, S, (D + 3) * 8), dtype=torch.float32, device=s_points.device)
+        _call("mcp_pointconv_agg", s_points, B, N, S, D, idx.shape[-1], _lib.fptr(s_xyz), _lib.fptr(new_xyz), _lib.fptr(s_points),
+              _lib.iptr(idx), _lib.fptr(w0), _lib.fptr(b0), _lib.fptr(w1), _lib.fptr(b1), _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(out))
+        return out
+
     def chamfer(self, x, y):
         """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor."""
         B, N, _ = x.shape
@@ -144,7 +153,7 @@ def set_backend(b):
 
 
 # ---- instrumentation passthrough (bench.py) ----
-KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7}
+KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7, "pointconv": 8}
 
 
 def prof_enable(kernel_name):

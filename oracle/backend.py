@@ -60,5 +60,16 @@ class OracleBackend:
         x = F.leaky_relu(F.linear(x, wmlp, bmlp), 0.1)
         return x.max(dim=2)[0]
 
+    def pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
+        """Unfused restatement of mocopci.py:1218-1266 + :1289-1300 + :1330-1335."""
+        F = torch.nn.functional
+        B, S, _ = new_xyz.shape
+        g_xyz = orc.group_rows(s_xyz, idx.int()) - new_xyz.unsqueeze(2)
+        new_points = torch.cat([g_xyz, orc.group_rows(s_points, idx.int())], dim=-1)
+        w = g_xyz
+        for ww, bb in ((w0, b0), (w1, b1), (w2, b2)):
+            w = torch.relu(F.linear(w, ww, bb))
+        return torch.matmul(new_points.transpose(2, 3), w).reshape(B, S, -1)
+
     def chamfer(self, x, y):
         return torch.tensor(orc.chamfer(x, y), dtype=torch.float32)

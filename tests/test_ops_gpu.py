@@ -206,3 +206,19 @@ def test_knn_cosine_bit_exact(q, n, c, k):
     gi_, gd = ops.backend().knn_cosine(qf.to(DEV), rf.to(DEV), k, return_dist=True)
     assert torch.equal(gi_.cpu(), wi)
     assert torch.equal(gd.cpu(), wd)
+
+
+@pytest.mark.parametrize("n,s,d", [(8192, 8192, 32), (2048, 512, 128), (256, 64, 512), (500, 77, 5)])
+def test_pointconv_agg_matches_unfused_oracle(n, s, d):
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(n + d)
+    B = 2
+    xyz = cloud(91, B, n)
+    new_xyz = xyz[:, :s].contiguous()
+    pts = torch.randn(B, n, d, generator=g)
+    idx = orc.knn(new_xyz, xyz, 32)
+    wn = [torch.randn(8, 3, generator=g) * 0.3, torch.randn(8, generator=g) * 0.1, torch.randn(8, 8, generator=g) * 0.3,
+          torch.randn(8, generator=g) * 0.1, torch.randn(8, 8, generator=g) * 0.3, torch.randn(8, generator=g) * 0.1]
+    want = OracleBackend().pointconv_agg(xyz, new_xyz, pts, idx, *wn)
+    got = ops.backend().pointconv_agg(*[t.to(DEV) for t in (xyz, new_xyz, pts, idx, *wn)]).cpu()
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-4)
