@@ -217,10 +217,10 @@ class MoCoPCI(nn.Module):
         xn = self.bn_eval(x, prefix + ".norm1", 1e-5)
         xr = torch.flip(xn, dims=[1])
         a = prefix + ".attn_feats"
-        q = self.lin(xn, a + ".q").reshape(B, Fr, N, 4, C).permute(0, 1, 3, 2, 4)
-        kv = self.lin(xr, a + ".kv").reshape(B, Fr, N, 2, 4, C).permute(3, 0, 1, 4, 2, 5)
-        o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=C ** -0.5)      # (B,2,4,N,C)
-        o = self.lin(o.sum(dim=1), a + ".proj")                                   # (B,4,N,C)
+        q = self.lin(xn, a + ".q").reshape(B * Fr, N, 4, C).permute(0, 2, 1, 3)
+        kv = self.lin(xr, a + ".kv").reshape(B * Fr, N, 2, 4, C).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=C ** -0.5)      # (B*2,4,N,C)
+        o = self.lin(o.reshape(B, Fr, 4, N, C).sum(dim=1), a + ".proj")           # (B,4,N,C)
         t = prefix + ".trans_block_2"
         xa = self.lin(F.prelu(self.lin(o, t + ".fc1"), P[t + ".act.weight"]), t + ".fc2")
         frames = self.lin(xa, prefix + ".mapping_xyz")
@@ -240,10 +240,11 @@ class MoCoPCI(nn.Module):
         xr = torch.flip(xn, dims=[1])
         a = prefix + ".attn_feats"
         hd = C // heads
-        q = self.lin(xn, a + ".q").reshape(B, Fr, N, heads, hd).permute(0, 1, 3, 2, 4)
-        kv = self.lin(xr, a + ".kv").reshape(B, Fr, N, 2, heads, hd).permute(3, 0, 1, 4, 2, 5)
-        o = F.scaled_dot_product_attention(q, kv[0], kv[1])                       # (B,5,H,N,hd)
-        o = self.lin(o.permute(0, 1, 3, 2, 4).reshape(B, Fr, N, C), a + ".proj")
+        # 4-D (batch*frames, heads, N, hd) so SDPA can pick a fused kernel instead of the math path
+        q = self.lin(xn, a + ".q").reshape(B * Fr, N, heads, hd).permute(0, 2, 1, 3)
+        kv = self.lin(xr, a + ".kv").reshape(B * Fr, N, 2, heads, hd).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1])                       # (B*5,H,N,hd)
+        o = self.lin(o.permute(0, 2, 1, 3).reshape(B, Fr, N, C), a + ".proj")
         xn = xn + o
         xb = self.mlp_t(prefix + ".mlp", self.bn_eval(xn, prefix + ".norm2", 1e-5))
         x = x + xb

@@ -222,3 +222,16 @@ def test_pointconv_agg_matches_unfused_oracle(n, s, d):
     want = OracleBackend().pointconv_agg(xyz, new_xyz, pts, idx, *wn)
     got = ops.backend().pointconv_agg(*[t.to(DEV) for t in (xyz, new_xyz, pts, idx, *wn)]).cpu()
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-4)
+
+
+def test_compat_helpers_keep_reference_signatures():
+    from mocopci_amd import compat
+    xyz, new_xyz = cloud(95, 2, 700).to(DEV), cloud(96, 2, 300).to(DEV)
+    idx = compat.knn_point(16, xyz, new_xyz)
+    assert idx.dtype == torch.int64 and idx.shape == (2, 300, 16)
+    assert torch.equal(idx.cpu().int(), orc.knn(new_xyz.cpu(), xyz.cpu(), 16))
+    g = compat.index_points_group(xyz, idx)
+    assert g.shape == (2, 300, 16, 3) and torch.equal(g.cpu(), orc.group_rows(xyz.cpu(), idx.cpu().int()))
+    d, i, _ = compat.knn_points(new_xyz, xyz, K=4)
+    wi, wd = orc.knn(new_xyz.cpu(), xyz.cpu(), 4, mode=1, return_dist=True)
+    assert torch.equal(i.cpu().int(), wi) and torch.equal(d.cpu(), wd)
