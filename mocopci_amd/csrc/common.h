@@ -45,14 +45,16 @@ __device__ __forceinline__ uint32_t mcp_row_max_u32(uint32_t v) {
     t = mcp_dpp<0x140>(v); v = v > t ? v : t;  // row_mirror
     return v;
 }
-// max over the whole wave, returned wave-uniform
+// max over the whole wave, returned wave-uniform: 4 row steps, then row_bcast15 / row_bcast31 carry the
+// row maxima forward so that lane 63 holds the wave maximum
 __device__ __forceinline__ uint32_t mcp_wave_max_u32(uint32_t v) {
     v = mcp_row_max_u32(v);
-    uint32_t a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
-    uint32_t c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
-    a = a > b ? a : b;
-    c = c > d ? c : d;
-    return a > c ? a : c;
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1,3
+    v = v > t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2,3
+    v = v > t ? v : t;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // ---- host-side helpers ----

@@ -19,7 +19,21 @@
 
 #include "common.h"
 
+// workgroup shape for 4 / 8 points per reference thread (T = 1024 >> J, P points per physical thread)
+#ifndef MCP_FPS_J8
+#define MCP_FPS_J8 1
+#endif
+#ifndef MCP_FPS_J4
+#define MCP_FPS_J4 1
+#endif
+#define MCP_FPS_T8 (1024 >> MCP_FPS_J8)
+#define MCP_FPS_P8 (8 << MCP_FPS_J8)
+#define MCP_FPS_T4 (1024 >> MCP_FPS_J4)
+#define MCP_FPS_P4 (4 << MCP_FPS_J4)
+
 namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t fps_sec(uint32_t k, int L) {
     if (L == 0) return k;
@@ -32,19 +46,21 @@ __device__ __forceinline__ uint32_t fps_unsec(uint32_t sec, int L) {
     return vt | ((sec & ((1u << (32 - L)) - 1u)) << L);
 }
 
-// T threads, P points per thread (k = tid + T*j).  FAST: T == reference block size, so a
-// physical thread is exactly one reference thread and the in-thread scan is the reference's
-// strict-'>' float scan.  Otherwise the in-thread scan also uses the (ord, ~sec) pair.
-template <int T, int P, bool FAST, bool LDS_XYZ>
+// T threads, P points per thread (k = tid + T*p).  The reference block has bs = 2^L threads; T = bs >> J.
+// J == 0: a physical thread is exactly one reference thread and its strict-'>' scan returns the first
+// maximum in ascending p.  J == 1 (T = bs/2): a thread holds two reference threads (even p -> tid,
+// odd p -> tid + T); bitrev_L(tid + T) = bitrev_L(tid) + 1, so among equal values the even-p points win,
+// each group in ascending p.  GENERIC (n < 64): every compare uses the full (ord, ~sec) pair.
+template <int T, int P, int J, bool GENERIC, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, const float *__restrict__ xyz,
                                                          float *__restrict__ temp, int *__restrict__ idxs) {
     constexpr int W = T / 64;
     extern __shared__ float4 smem_f4[];
-    uint2 *slots = reinterpret_cast<uint2 *>(smem_f4);        // [2][16]
-    float *sxyz = reinterpret_cast<float *>(smem_f4) + 2 * 16 * 2;  // [n*3] when LDS_XYZ
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_f4);  // [3] rotating max slots (+pad to 64 B)
+    float *sxyz = reinterpret_cast<float *>(smem_f4) + 16;                        // [n*3] when LDS_XYZ
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     xyz += (size_t)blockIdx.x * n * 3;
     temp += (size_t)blockIdx.x * n;
     idxs += (size_t)blockIdx.x * m;
@@ -65,11 +81,12 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
     if (LDS_XYZ) {
         for (int i = tid; i < n * 3; i += T) sxyz[i] = xyz[i];
     }
-    if (tid < 32) slots[tid] = make_uint2(0u, 0u);
+    if (tid < 3) slots[tid] = 0ull;
     if (tid == 0) idxs[0] = 0;
     __syncthreads();
 
     int old = 0;
+    int s_cur = 0, s_nxt = 1;
     for (int j = 1; j < m; ++j) {
         float x1, y1, z1;
         if (LDS_XYZ) {
@@ -78,20 +95,41 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
             x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
         }
         uint32_t hi, lo;
-        if (FAST) {
-            float best = -1.0f;
-            uint32_t bsec = 0;
+        if (!GENERIC) {
+            // track only the maximum VALUE in the scan (packed fp32 math); which point holds it is found afterwards
+            float best;
+            if constexpr (P >= 2) {
+                const f2 c0 = {x1, x1}, c1 = {y1, y1}, c2 = {z1, z1};
+                f2 m2 = {-1.0f, -1.0f};
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                float d = mcp_sqdist3(px[p], py[p], pz[p], x1, y1, z1);
-                float d2 = fminf(d, pt[p]);
-                pt[p] = d2;
-                bool gt = d2 > best;
-                bsec = gt ? nsec[p] : bsec;
-                best = gt ? d2 : best;
+                for (int p = 0; p < P; p += 2) {
+                    const f2 dx = f2{px[p], px[p + 1]} - c0, dy = f2{py[p], py[p + 1]} - c1, dz = f2{pz[p], pz[p + 1]} - c2;
+                    const f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    pt[p] = fminf(d.x, pt[p]);
+                    pt[p + 1] = fminf(d.y, pt[p + 1]);
+                    m2.x = fmaxf(m2.x, pt[p]);
+                    m2.y = fmaxf(m2.y, pt[p + 1]);
+                }
+                best = fmaxf(m2.x, m2.y);
+            } else {
+                pt[0] = fminf(mcp_sqdist3(px[0], py[0], pz[0], x1, y1, z1), pt[0]);
+                best = fmaxf(-1.0f, pt[0]);
             }
             hi = mcp_ord(best);
-            lo = bsec;
+            const uint32_t whi = mcp_wave_max_u32(hi);
+            // tie order inside the thread: reverse-priority assignment chain, highest priority assigned last
+            uint32_t bsec = 0;
+            if constexpr (J == 1) {
+#pragma unroll
+                for (int p = P - 1; p >= 1; p -= 2) bsec = pt[p] == best ? nsec[p] : bsec;  // odd p (reference thread tid+T)
+#pragma unroll
+                for (int p = P - 2; p >= 0; p -= 2) bsec = pt[p] == best ? nsec[p] : bsec;  // even p (reference thread tid)
+            } else {
+#pragma unroll
+                for (int p = P - 1; p >= 0; --p) bsec = pt[p] == best ? nsec[p] : bsec;
+            }
+            lo = hi == whi ? bsec : 0u;
+            hi = whi;
         } else {
             hi = 0; lo = 0;
 #pragma unroll
@@ -104,19 +142,20 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
                 lo = gt ? nsec[p] : lo;
                 hi = gt ? h : hi;
             }
+            const uint32_t whi = mcp_wave_max_u32(hi);
+            lo = hi == whi ? lo : 0u;
+            hi = whi;
         }
-        // wave reduce: max hi, then max lo among lanes holding that hi
-        uint32_t whi = mcp_wave_max_u32(hi);
-        uint32_t wlo = mcp_wave_max_u32(hi == whi ? lo : 0u);
+        uint32_t wlo = mcp_wave_max_u32(lo);
         if (W > 1) {
-            uint2 *sl = slots + (j & 1) * 16;
-            if (lane == 0) sl[wave] = make_uint2(wlo, whi);
+            // cross-wave: one LDS atomic max per wave on a rotating slot, one barrier, one broadcast read
+            if (lane == 0) atomicMax(&slots[s_cur], ((unsigned long long)hi << 32) | wlo);
+            if (tid == 0) slots[s_nxt] = 0ull;
             __syncthreads();
-            uint2 e = sl[lane & 15];
-            uint32_t ghi = mcp_row_max_u32(e.y);
-            uint32_t glo = mcp_row_max_u32(e.y == ghi ? e.x : 0u);
-            whi = __builtin_amdgcn_readfirstlane((int)ghi);
-            wlo = __builtin_amdgcn_readfirstlane((int)glo);
+            wlo = (uint32_t)slots[s_cur];
+            const int s_new = 3 - s_cur - s_nxt;
+            s_cur = s_nxt;
+            s_nxt = s_new;
         }
         old = (int)fps_unsec(~wlo, L);
         if (tid == 0) idxs[j] = old;
@@ -176,16 +215,20 @@ int ref_block_log2(int n) {
     return pow_2;
 }
 
-template <int T, int P, bool FAST>
+template <int T, int P, int J, bool GENERIC>
 int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
-    const size_t slot_bytes = 2 * 16 * sizeof(uint2);
+    const size_t slot_bytes = 64;
     const size_t xyz_bytes = (size_t)n * 3 * sizeof(float);
     if (xyz_bytes + slot_bytes <= 150 * 1024) {
-        auto kern = fps_resident_kernel<T, P, FAST, true>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        auto kern = fps_resident_kernel<T, P, J, GENERIC, true>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
         hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + xyz_bytes, s, n, m, L, xyz, temp, idx);
     } else {
-        hipLaunchKernelGGL((fps_resident_kernel<T, P, FAST, false>), dim3(b), dim3(T), slot_bytes, s, n, m, L, xyz, temp, idx);
+        hipLaunchKernelGGL((fps_resident_kernel<T, P, J, GENERIC, false>), dim3(b), dim3(T), slot_bytes, s, n, m, L, xyz, temp, idx);
     }
     return mcp_launch_status();
 }
@@ -203,21 +246,22 @@ MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz
     if (bs >= 64) {
         const int P = (n + bs - 1) / bs;
         if (bs == 1024) {
-            if (P <= 1) rc = launch_resident<1024, 1, true>(b, n, m, L, xyz, temp, idx, s);
-            else if (P <= 2) rc = launch_resident<1024, 2, true>(b, n, m, L, xyz, temp, idx, s);
-            else if (P <= 4) rc = launch_resident<1024, 4, true>(b, n, m, L, xyz, temp, idx, s);
-            else if (P <= 8) rc = launch_resident<1024, 8, true>(b, n, m, L, xyz, temp, idx, s);
-            else if (P <= 16) rc = launch_resident<1024, 16, true>(b, n, m, L, xyz, temp, idx, s);
+            // half-size workgroups (J = 1) from 4 points per reference thread up: fewer waves in the reduction
+            if (P <= 1) rc = launch_resident<1024, 1, 0, false>(b, n, m, L, xyz, temp, idx, s);
+            else if (P <= 2) rc = launch_resident<1024, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
+            else if (P <= 4) rc = launch_resident<MCP_FPS_T4, MCP_FPS_P4, MCP_FPS_J4, false>(b, n, m, L, xyz, temp, idx, s);
+            else if (P <= 8) rc = launch_resident<MCP_FPS_T8, MCP_FPS_P8, MCP_FPS_J8, false>(b, n, m, L, xyz, temp, idx, s);
+            else if (P <= 16) rc = launch_resident<1024, 16, 0, false>(b, n, m, L, xyz, temp, idx, s);
             else {
                 hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, s, n, m, L, xyz, temp, idx);
                 rc = mcp_launch_status();
             }
-        } else if (bs == 512) rc = launch_resident<512, 2, true>(b, n, m, L, xyz, temp, idx, s);
-        else if (bs == 256) rc = launch_resident<256, 2, true>(b, n, m, L, xyz, temp, idx, s);
-        else if (bs == 128) rc = launch_resident<128, 2, true>(b, n, m, L, xyz, temp, idx, s);
-        else rc = launch_resident<64, 2, true>(b, n, m, L, xyz, temp, idx, s);
+        } else if (bs == 512) rc = launch_resident<512, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
+        else if (bs == 256) rc = launch_resident<256, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
+        else if (bs == 128) rc = launch_resident<128, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
+        else rc = launch_resident<64, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
     } else {
-        rc = launch_resident<64, 1, false>(b, n, m, L, xyz, temp, idx, s);  // n < 64
+        rc = launch_resident<64, 1, 0, true>(b, n, m, L, xyz, temp, idx, s);  // n < 64
     }
     mcp_prof_end(MCP_KERNEL_FPS, s);
     return rc;

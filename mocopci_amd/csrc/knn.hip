@@ -136,18 +136,38 @@ __global__ __launch_bounds__(64 * SPLIT) void knn_small_kernel(int q, int n, int
         }
         __builtin_amdgcn_wave_barrier();
         const int base = t * TILE;
-#pragma unroll 4
-        for (int r = 0; r < TILE; ++r) {
-            const float d = pair_dist<MODE>(qx, qy, qz, qn, tile[cur][r]);
-            if (__builtin_amdgcn_ballot_w64(d < tau)) {
-                u64 key = ((u64)mcp_ord(d) << 32) | (uint32_t)(base + r);
-                key = d < tau ? key : KEY_INF;
-                a[3] = key < a[3] ? key : a[3];
-                ce_asc(a[2], a[3]);
-                ce_asc(a[1], a[2]);
-                ce_asc(a[0], a[1]);
-                tau = tau_of(a[3]);
+        constexpr int G = 8;  // references per group: loads of group g+1 are in flight under the math of group g
+        float4 rc[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) rc[u] = tile[cur][u];
+        for (int r0 = 0; r0 < TILE; r0 += G) {
+            float4 rn[G];
+            const int rnext = r0 + G < TILE ? r0 + G : r0;
+#pragma unroll
+            for (int u = 0; u < G; ++u) rn[u] = tile[cur][rnext + u];
+            float d[G];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                d[u] = pair_dist<MODE>(qx, qy, qz, qn, rc[u]);
+                any |= d[u] < tau;
             }
+            if (__builtin_amdgcn_ballot_w64(any)) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    if (__builtin_amdgcn_ballot_w64(d[u] < tau)) {
+                        u64 key = ((u64)mcp_ord(d[u]) << 32) | (uint32_t)(base + r0 + u);
+                        key = d[u] < tau ? key : KEY_INF;
+                        a[3] = key < a[3] ? key : a[3];
+                        ce_asc(a[2], a[3]);
+                        ce_asc(a[1], a[2]);
+                        ce_asc(a[0], a[1]);
+                        tau = tau_of(a[3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) rc[u] = rn[u];
         }
         if (t + 1 < t1) {
             __builtin_amdgcn_wave_barrier();
@@ -251,16 +271,29 @@ __global__ __launch_bounds__(64 * SPLIT) void knn_queue_kernel(int q, int n, int
         }
         __builtin_amdgcn_wave_barrier();
         const int base = t * TILE;
-        for (int r0 = 0; r0 < TILE; r0 += CHK) {
+        // software pipeline over groups of CHK references: the next group's float4s are in flight while this
+        // group's distances and queue pushes run (the compiler will not hoist LDS reads above the queue writes)
+        float4 rc[CHK];
 #pragma unroll
-            for (int r = r0; r < r0 + CHK; ++r) {
-                const float d = pair_dist<MODE>(qx, qy, qz, qn, tile[cur][r]);
-                if (d < tau) {
-                    queue[cnt][lane] = make_uint2(__float_as_uint(d), (uint32_t)(base + r));
+        for (int u = 0; u < CHK; ++u) rc[u] = tile[cur][u];
+        for (int r0 = 0; r0 < TILE; r0 += CHK) {
+            float4 rn[CHK];
+            const int rnext = r0 + CHK < TILE ? r0 + CHK : r0;  // last group re-reads itself (harmless)
+#pragma unroll
+            for (int u = 0; u < CHK; ++u) rn[u] = tile[cur][rnext + u];
+            float d[CHK];
+#pragma unroll
+            for (int u = 0; u < CHK; ++u) d[u] = pair_dist<MODE>(qx, qy, qz, qn, rc[u]);
+#pragma unroll
+            for (int u = 0; u < CHK; ++u) {
+                if (d[u] < tau) {
+                    queue[cnt][lane] = make_uint2(__float_as_uint(d[u]), (uint32_t)(base + r0 + u));
                     ++cnt;
                 }
             }
             if (__builtin_amdgcn_ballot_w64(cnt > QS - CHK)) flush();
+#pragma unroll
+            for (int u = 0; u < CHK; ++u) rc[u] = rn[u];
         }
         if (t + 1 < t1) {
             __builtin_amdgcn_wave_barrier();

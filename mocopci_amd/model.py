@@ -121,36 +121,64 @@ class MoCoPCI(nn.Module):
         agg = be.pointconv_agg(s_xyz, new_xyz, s_points.contiguous(), idx, *wn)      # (B,S,(3+D)*8)
         return leaky(self.lin(agg, prefix + ".linear"))
 
-    def pointconv_d(self, prefix, npoint, xyz, points):
+    def fps_gather(self, xyz, npoint):
+        """furthest_point_sample + index_points_gather (mocopci.py:1378-1379)."""
         be = ops.backend()
-        fps_idx = be.fps(xyz, npoint)
-        new_xyz = be.group_rows(xyz, fps_idx)                             # (B,npoint,3)
-        return new_xyz, self.pointconv(prefix, xyz, new_xyz, points)
+        return be.group_rows(xyz, be.fps(xyz, npoint))
+
+    def side_stream(self, device):
+        """Second HIP stream for the serial FPS chains (one workgroup per batch element, latency-bound): they
+        overlap with the KNN / PointConv work of the main stream.  CPU backends run inline."""
+        if device.type != "cuda":
+            return None
+        if getattr(self, "_side", None) is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def run_encoder(self, xyz):
-        """PointConvEncoder.forward (mocopci.py:438-468), color == xyz."""
+        """PointConvEncoder.forward (mocopci.py:438-468), color == xyz.  The four FPS levels depend only on the
+        coordinates, so the whole sampling pyramid is issued up front on the side stream."""
         p = "encoder."
+        side = self.side_stream(xyz.device)
+        if side is not None:
+            main = torch.cuda.current_stream(xyz.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pc1 = self.fps_gather(xyz, 2048)
+                pc2 = self.fps_gather(pc1, 512)
+                pc3 = self.fps_gather(pc2, 256)
+                pc4 = self.fps_gather(pc3, 64)
+                done = torch.cuda.Event()
+                done.record(side)
+        else:
+            pc1 = self.fps_gather(xyz, 2048)
+            pc2 = self.fps_gather(pc1, 512)
+            pc3 = self.fps_gather(pc2, 256)
+            pc4 = self.fps_gather(pc3, 64)
         f0 = self.conv1d_block(xyz, p + "level0_lift")
         f0 = self.pointconv(p + "level0", xyz, xyz, f0)
         f0_1 = self.conv1d_block(f0, p + "level0_1")
-        pc1, f1 = self.pointconv_d(p + "level1", 2048, xyz, f0_1)
+        if side is not None:
+            main.wait_event(done)
+        f1 = self.pointconv(p + "level1", xyz, pc1, f0_1)
         f1 = self.conv1d_block(f1, p + "level1_0")
         f1_2 = self.conv1d_block(f1, p + "level1_1")
-        pc2, f2 = self.pointconv_d(p + "level2", 512, pc1, f1_2)
+        f2 = self.pointconv(p + "level2", pc1, pc2, f1_2)
         f2 = self.conv1d_block(f2, p + "level2_0")
         f2_3 = self.conv1d_block(f2, p + "level2_1")
-        pc3, f3 = self.pointconv_d(p + "level3", 256, pc2, f2_3)
+        f3 = self.pointconv(p + "level3", pc2, pc3, f2_3)
         f3 = self.conv1d_block(f3, p + "level3_0")
         f3_4 = self.conv1d_block(f3, p + "level3_1")
-        pc4, f4 = self.pointconv_d(p + "level4", 64, pc3, f3_4)
+        f4 = self.pointconv(p + "level4", pc3, pc4, f3_4)
         return [xyz, pc1, pc2, pc3, pc4], [f0, f1, f2, f3, f4]
 
-    def cross(self, xyz1, xyz2, points1, points2, knn1, knn2, pos, mlp, sorted_p3d):
+    def cross(self, xyz1, xyz2, points1, points2, knn1, knn2, pos, mlp, sorted_p3d, idx_c=None):
         """cost-volume cross() (pointconv_util.py:750-781; :894-922 with pytorch3d knn_points;
         :1126-1161).  16 feature-cosine neighbours then 16 xyz neighbours of set 2 per point of
         set 1, LeakyReLU(g2 + p1 + pos(dxyz)), 1x1 convs, max over the 32 neighbours."""
         be = ops.backend()
-        idx_c = be.knn_cosine(knn1, knn2, 16)
+        if idx_c is None:  # depends only on the two feature sets: callers that reuse them pass it in
+            idx_c = be.knn_cosine(knn1, knn2, 16)
         if sorted_p3d:
             # pointconv_util.py:910-911: knn_points(xyz2, xyz1) -- QUERY = xyz2, REF = xyz1 -- and the
             # resulting indices (into xyz1) are then used to index set 2.  Reproduced as is.
@@ -275,12 +303,18 @@ class MoCoPCI(nn.Module):
         bid_mlp = [b + ".mlp.0"]
         fe_mlp = [fe + ".mlp.0"]
         fes = []
+        # The 16 feature-cosine neighbours depend only on the encoder features (f1_0, f2_0), not on the warped
+        # coordinates: one search serves all nine cross() calls of this level.  The batch holds both decoder
+        # directions, so the (f2_0 -> f1_0) search is the same result with its halves swapped.
+        half = f1_0.shape[0] // 2
+        idx_c12 = ops.backend().knn_cosine(f1_0, f2_0, 16)
+        idx_c21 = torch.cat([idx_c12[half:], idx_c12[:half]], dim=0)
         for up in up_frames:
             pc2w = self.warp(pc1, pc2, up)
-            n1 = self.cross(pc1, pc2w, t11_1, t22_2, f1_0, f2_0, b + ".pos", bid_mlp, True)
-            n2 = self.cross(pc2w, pc1, t11_2, t22_1, f2_0, f1_0, b + ".pos", bid_mlp, True)
+            n1 = self.cross(pc1, pc2w, t11_1, t22_2, f1_0, f2_0, b + ".pos", bid_mlp, True, idx_c12)
+            n2 = self.cross(pc2w, pc1, t11_2, t22_1, f2_0, f1_0, b + ".pos", bid_mlp, True, idx_c21)
             fes.append(self.cross(pc1, pc2w, self.lin(n1, fe + ".conv1"), self.lin(n2, fe + ".conv2"), f1_0, f2_0,
-                                  fe + ".pos", fe_mlp, False))
+                                  fe + ".pos", fe_mlp, False, idx_c12))
         x = torch.stack([n1, *fes, n2], dim=1) + time_enc                          # (B,5,N,C)
         xf, frames = self.multi_frame_att(prefix + ".cross_block", x)              # (B,3,N,latent),(B,3,N,3)
         feat_frames = self.conv1d_block(xf, prefix + ".downsample")                # (B,3,N,C)
@@ -312,11 +346,13 @@ class MoCoPCI(nn.Module):
             P[key] = ((self.W(conv) * scale[:, None]).contiguous(), ((self.Bv(conv) - P[bn + ".running_mean"]) * scale + P[bn + ".bias"]).contiguous())
         return P[key]
 
-    def fusion(self, p1, p2, k=32):
+    def fusion(self, p1, p2, k=32, idx_self=None):
         """MultiFrameEstimatier.knn_group + fusion (mocopci.py:798-819).  p1, p2 (B,N,3)."""
         be = ops.backend()
         m = "multi_frame_inference.conv."
-        idx = torch.cat([be.knn(p1, p1, k), be.knn(p1, p2, k)], dim=-1)            # (B,N,2k) both index p2
+        if idx_self is None:
+            idx_self = be.knn(p1, p1, k)
+        idx = torch.cat([idx_self, be.knn(p1, p2, k)], dim=-1)                     # (B,N,2k) both index p2
         wb = [t for ci, bi in ((0, 1), (3, 4), (6, 7)) for t in self.folded_conv_bn(m + str(ci), m + str(bi), 1e-3)]
         return be.fusion_mlp(p1, p2.contiguous(), idx, *wb)
 
@@ -385,12 +421,25 @@ class MoCoPCI(nn.Module):
         warped = pc0 + up_flow
         # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022)
         wf = f0 + F.adaptive_avg_pool1d(up_flow, f0.shape[-1])
+        side = self.side_stream(dev)
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                down = self.fps_gather(warped, 2048)
+                done = torch.cuda.Event()
+                done.record(side)
+        else:
+            down = self.fps_gather(warped, 2048)
         wf = self.conv1d_block(wf, m + "rlevel0")
-        down, dfeat = self.pointconv_d(m + "level1", 2048, warped, wf)
+        idx_self = ops.backend().knn(warped, warped, 32)      # fusion's self search: independent of the refine branch
+        if side is not None:
+            main.wait_event(done)
+        dfeat = self.pointconv(m + "level1", warped, down, wf)
         shape = self.transformer_block(m + "shape1", dfeat, down)
         upf = ops.backend().interp3(warped, down, shape)
         refine = self.lin(F.relu(self.lin(upf, m + "pred.0")), m + "pred.2")       # (3B,N,3)
-        final = self.fusion(warped, refine)
+        final = self.fusion(warped, refine, idx_self=idx_self)
         return [final[:B], final[B:2 * B], final[2 * B:]]
 
     def forward(self, xyz1, xyz2, gt=None, t=None, train=False):

@@ -19,7 +19,7 @@ def wrap(name):
         acc[name] += s.elapsed_time(e); cnt[name] += 1
         return r
     setattr(net, name, w)
-for n in ["pointconv", "pointconv_d", "cross", "interp", "warp", "ei_crossformer", "cross_frame_att", "multi_frame_att",
+for n in ["pointconv", "fps_gather", "cross", "interp", "warp", "ei_crossformer", "cross_frame_att", "multi_frame_att",
           "transformer_block", "fusion"]:
     wrap(n)
 for _ in range(2): net(x1, x2)
