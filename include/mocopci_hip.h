@@ -99,6 +99,23 @@ int mcp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
 int mcp_knn(int b, int q, int n, int k, int dist_form, const float *query, const float *ref, int *idx, float *dist,
             mcp_stream_t stream);
 
+/* Spatially pruned variant of mcp_knn for large clouds: identical results (same definition, same fp32
+ * canon), but queries and references are given in Morton order and each tile of 128 sorted references
+ * has a bounding box, so a wave visits tiles by ascending lower bound and stops early.
+ *   mcp_morton_codes: xyz (B,N,3), box (B,6) = per-batch (min xyz, max xyz) -> codes (B,N) int32 (30 bit);
+ *                     the caller sorts by code (any stable or unstable sort) to get a permutation.
+ *   mcp_tile_boxes:   sorted_xyz (B,N,3) -> boxes (B,ceil(N/128),6).
+ *   mcp_knn_pruned:   query_sorted (B,Q,3) with qperm (B,Q) = original row of each sorted query (NULL = identity),
+ *                     ref_sorted (B,N,3) with rperm (B,N) = original index of each sorted reference, boxes as above
+ *                     -> idx (B,Q,K) ORIGINAL reference indices at ORIGINAL query rows (+ dist).  4 < K <= 32, N <= 65536.
+ *   mcp_build_cloud:  all of the above in one launch for N <= 16384 (bbox, isotropic Morton keys, in-LDS sort, gather,
+ *                     tile boxes): xyz (B,N,3) -> sorted_xyz (B,N,3), perm (B,N) int32, boxes (B,ceil(N/128),6). */
+int mcp_build_cloud(int b, int n, const float *xyz, float *sorted_xyz, int *perm, float *boxes, mcp_stream_t stream);
+int mcp_morton_codes(int b, int n, const float *xyz, const float *box, int *codes, mcp_stream_t stream);
+int mcp_tile_boxes(int b, int n, const float *sorted_xyz, float *boxes, mcp_stream_t stream);
+int mcp_knn_pruned(int b, int q, int n, int k, int dist_form, const float *query_sorted, const int *qperm,
+                   const float *ref_sorted, const int *rperm, const float *boxes, int *idx, float *dist, mcp_stream_t stream);
+
 /* knn_point_cosine(nsample, xyz, new_xyz) (pointconv_util.py:111-153) on channel-last features:
  * qfeat (B,Q,C), rfeat (B,N,C) -> idx (B,Q,K) (and dist if non-NULL): the K smallest of
  * d = 1 - <q^,r^>, x^ = x / sqrt(sum x^2 + 1e-8), under the order (d, index), ascending.

@@ -27,6 +27,10 @@ SIGNATURES = {
     "mcp_three_interpolate": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_three_interpolate_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_knn": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_build_cloud": [_i, _i, _p, _p, _p, _p, _p],
+    "mcp_morton_codes": [_i, _i, _p, _p, _p, _p],
+    "mcp_tile_boxes": [_i, _i, _p, _p, _p],
+    "mcp_knn_pruned": [_i] * 5 + [_p] * 8,
     "mcp_knn_cosine": [_i] * 5 + [_p] * 6,
     "mcp_group_rows": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_interp3": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],

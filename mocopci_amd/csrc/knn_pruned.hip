@@ -1,0 +1,527 @@
+// knn_pruned.hip -- exact KNN with spatial pruning for large reference sets (gfx950).
+//
+// Same result definition as knn.hip / the oracle (K smallest under (distance, index), ascending,
+// distances in the shared fp32 canon), but the reference cloud is visited selectively:
+//   * host side (mocopci_amd/ops.py) Morton-sorts queries and references once per cloud;
+//     mcp_morton_codes / mcp_tile_boxes below produce the sort keys and one axis-aligned box
+//     per tile of PT consecutive sorted references;
+//   * a wave owns 64 consecutive SORTED queries (a compact region), computes the lower bound of the
+//     squared distance from its query box to every tile box, and visits tiles in ascending bound
+//     order; it stops as soon as the smallest unvisited bound exceeds the largest per-lane K-th
+//     distance plus a slack that covers the rounding of the distance expression -- every skipped
+//     reference would have failed the per-lane "d <= tau" test anyway, so the output is bit-identical
+//     to the exhaustive scan;
+//   * within a visited tile the scan / threshold queue / register bitonic merge are those of
+//     knn.hip; candidates carry the ORIGINAL reference index (tie order is defined on it), and
+//     "d <= tau" (not "<") is used because tiles are no longer visited in index order;
+//   * results are written to the query's original row (qperm).
+// At N=8192 a wave scans ~1000 of the 8192 references.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr u64 KEY_INF = ~0ull;
+constexpr int PT = 128;      // references per tile
+constexpr int MAX_TPL = 8;   // tiles per lane -> up to 512 tiles (N <= 65536)
+
+__device__ __forceinline__ void ce_asc(u64 &a, u64 &b) {
+    const bool sw = b < a;
+    const u64 lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+__device__ __forceinline__ void ce_dir(u64 &a, u64 &b, bool up) {
+    const bool sw = up ? (b < a) : (a < b);
+    const u64 x = sw ? b : a, y = sw ? a : b;
+    a = x;
+    b = y;
+}
+template <int N>
+__device__ __forceinline__ void bitonic_sort(u64 (&v)[N]) {
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ j;
+                if (l > i) ce_dir(v[i], v[l], (i & k) == 0);
+            }
+}
+template <int K, int QS>
+__device__ __forceinline__ void merge_sorted(u64 (&a)[K], const u64 (&q)[QS]) {
+#pragma unroll
+    for (int i = K - QS; i < K; ++i) {
+        const u64 o = q[K - 1 - i];
+        a[i] = o < a[i] ? o : a[i];
+    }
+#pragma unroll
+    for (int j = K >> 1; j > 0; j >>= 1)
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int l = i ^ j;
+            if (l > i) ce_asc(a[i], a[l]);
+        }
+}
+__device__ __forceinline__ float tau_of(u64 kth) {
+    const uint32_t hi = (uint32_t)(kth >> 32);
+    return hi == 0xFFFFFFFFu ? INFINITY : mcp_unord(hi);
+}
+__device__ __forceinline__ float wave_minf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_maxf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- preprocessing kernels ------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+// 30-bit Morton code on the per-batch box [lo, hi] (box (B,6): lo xyz, hi xyz)
+__global__ __launch_bounds__(256) void morton_kernel(int n, const float *__restrict__ xyz, const float *__restrict__ box,
+                                                     int *__restrict__ codes) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *bx = box + b * 6;
+    const float *p = xyz + ((size_t)b * n + i) * 3;
+    // isotropic cells (one scale for the three axes): LiDAR clouds are flat, per-axis scaling would slice them
+    // into thin slabs with huge x/y extent
+    const float ext = fmaxf(fmaxf(bx[3] - bx[0], bx[4] - bx[1]), bx[5] - bx[2]);
+    uint32_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float t = ext > 0.f ? (p[a] - bx[a]) / ext : 0.f;
+        t = fminf(fmaxf(t * 1024.f, 0.f), 1023.f);
+        c[a] = (uint32_t)t;
+    }
+    codes[(size_t)b * n + i] = (int)(spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2));
+}
+// one wave per tile of PT sorted points: (lo xyz, hi xyz)
+__global__ __launch_bounds__(64) void tile_box_kernel(int n, int tiles, const float *__restrict__ sorted_xyz, float *__restrict__ boxes) {
+    const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = t * PT + lane; i < min(n, (t + 1) * PT); i += 64) {
+        const float *p = sorted_xyz + ((size_t)b * n + i) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], p[a]);
+            hi[a] = fmaxf(hi[a], p[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = wave_minf(lo[a]);
+        hi[a] = wave_maxf(hi[a]);
+    }
+    if (lane == 0) {
+        float *o = boxes + ((size_t)b * tiles + t) * 6;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+    }
+}
+
+// ---- fused cloud builder: bbox -> Morton keys -> LDS bitonic sort -> gather -> tile boxes ---------------------
+// One workgroup per batch element (N <= 16384: the (key << 32 | index) array lives in LDS).
+constexpr int BT = 1024;
+__global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int npow2, int tiles, const float *__restrict__ xyz,
+                                                         float *__restrict__ sorted_xyz, int *__restrict__ perm,
+                                                         float *__restrict__ boxes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dyn[];
+    // one dynamic LDS block: [0,512) reduction scratch + bbox, then the npow2 keys
+    float(*red)[BT / 64] = reinterpret_cast<float(*)[BT / 64]>(dyn);     // [6][16] floats = 384 B
+    float *bbox = reinterpret_cast<float *>(dyn) + 6 * (BT / 64);          // [6]
+    unsigned long long *keys = dyn + 64;                                   // 512 B in
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    xyz += (size_t)b * n * 3;
+    sorted_xyz += (size_t)b * n * 3;
+    perm += (size_t)b * n;
+    boxes += (size_t)b * tiles * 6;
+    // 1. bounding box of the cloud
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n; i += BT) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[(size_t)i * 3 + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = wave_minf(lo[a]);
+        hi[a] = wave_maxf(hi[a]);
+        if (lane == 0) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    }
+    __syncthreads();
+    if (tid < 6) {
+        float v = red[tid][0];
+        for (int w = 1; w < BT / 64; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+        bbox[tid] = v;
+    }
+    __syncthreads();
+    const float ext = fmaxf(fmaxf(bbox[3] - bbox[0], bbox[4] - bbox[1]), bbox[5] - bbox[2]);
+    // 2. keys: isotropic 10-bit cells (LiDAR clouds are flat: per-axis scaling would slice them into thin slabs)
+    for (int i = tid; i < npow2; i += BT) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            uint32_t c[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float t = ext > 0.f ? (xyz[(size_t)i * 3 + a] - bbox[a]) / ext : 0.f;
+                t = fminf(fmaxf(t * 1024.f, 0.f), 1023.f);
+                c[a] = (uint32_t)t;
+            }
+            const uint32_t code = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+            k = ((unsigned long long)code << 32) | (uint32_t)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    // 3. bitonic sort of (code, index) in LDS
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < npow2 / 2; p += BT) {
+                const int i = 2 * p - (p & (j - 1));  // element with bit j clear
+                const int l = i + j;
+                const unsigned long long x = keys[i], y = keys[l];
+                const bool up = (i & k) == 0;
+                if ((y < x) == up) { keys[i] = y; keys[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    // 4. permutation + sorted coordinates
+    for (int i = tid; i < n; i += BT) {
+        const int src = (int)(uint32_t)keys[i];
+        perm[i] = src;
+        sorted_xyz[(size_t)i * 3 + 0] = xyz[(size_t)src * 3 + 0];
+        sorted_xyz[(size_t)i * 3 + 1] = xyz[(size_t)src * 3 + 1];
+        sorted_xyz[(size_t)i * 3 + 2] = xyz[(size_t)src * 3 + 2];
+    }
+    // 5. one box per tile of PT sorted points (a wave per tile)
+    for (int t = wave; t < tiles; t += BT / 64) {
+        float tl[3] = {INFINITY, INFINITY, INFINITY}, th[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = t * PT + lane; i < min(n, (t + 1) * PT); i += 64) {
+            const int src = (int)(uint32_t)keys[i];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = xyz[(size_t)src * 3 + a];
+                tl[a] = fminf(tl[a], v);
+                th[a] = fmaxf(th[a], v);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            tl[a] = wave_minf(tl[a]);
+            th[a] = wave_maxf(th[a]);
+        }
+        if (lane == 0) {
+            float *o = boxes + (size_t)t * 6;
+            o[0] = tl[0]; o[1] = tl[1]; o[2] = tl[2]; o[3] = th[0]; o[4] = th[1]; o[5] = th[2];
+        }
+    }
+}
+
+// ---- the search ------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float qn, const float4 r) {
+    if (MODE == MCP_DIST_EXPANSION) return mcp_expdist(qx, qy, qz, qn, r.x, r.y, r.z, r.w);
+    return mcp_sqdist3(qx, qy, qz, r.x, r.y, r.z);
+}
+
+template <int K>
+struct PrunedLds {
+#ifndef MCP_PRUNED_QS
+#define MCP_PRUNED_QS 16
+#endif
+    static constexpr int QS = MCP_PRUNED_QS;
+    static constexpr int TILE_BYTES = PT * 16;      // float4 (x,y,z,|r|^2)
+    static constexpr int PERM_BYTES = PT * 4;       // original indices, stored [sub][PT/SUB]
+    static constexpr int QUEUE_BYTES = QS * 64 * 8;
+    static constexpr int WAVE_BYTES = TILE_BYTES + PERM_BYTES + QUEUE_BYTES;
+};
+
+// min over the SUB adjacent lanes that share a query
+template <int SUB>
+__device__ __forceinline__ float sub_min(float v) {
+    if (SUB >= 2) v = fminf(v, __uint_as_float(mcp_dpp<0xB1>(__float_as_uint(v))));  // quad_perm [1,0,3,2]
+    if (SUB >= 4) v = fminf(v, __uint_as_float(mcp_dpp<0x4E>(__float_as_uint(v))));  // quad_perm [2,3,0,1]
+    return v;
+}
+
+// SUB lanes cooperate on one query (64/SUB queries per wave): lane sub = lane % SUB scans references
+// r = sub (mod SUB) of every visited tile into its own K-list; the push threshold is the minimum of the
+// SUB K-th distances (any one list already holds K references below it, so nothing above can reach the
+// final K); the SUB lists are merged through DPP exchanges at the end.  More, shorter waves with smaller
+// query boxes: better pruning, latency and load balance than one lane per query.
+template <int K, int MODE, int SUB>
+__global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles, int kout, const float *__restrict__ query,
+                                                        const int *__restrict__ qperm, const float *__restrict__ ref,
+                                                        const int *__restrict__ rperm, const float *__restrict__ boxes,
+                                                        int *__restrict__ idx, float *__restrict__ dist) {
+    using L = PrunedLds<K>;
+    constexpr int QS = L::QS, CHK = 4, QPW = 64 / SUB, RPL = PT / SUB;  // queries per wave, references per lane per tile
+    extern __shared__ float4 smem_f4[];
+    const int lane = threadIdx.x;
+    char *wbase = reinterpret_cast<char *>(smem_f4);
+    float4 *tile = reinterpret_cast<float4 *>(wbase);
+    int *tperm = reinterpret_cast<int *>(wbase + L::TILE_BYTES);
+    uint2(*queue)[64] = reinterpret_cast<uint2(*)[64]>(wbase + L::TILE_BYTES + L::PERM_BYTES);
+
+    const int b = blockIdx.y;
+    const int sub = lane % SUB;
+    const int q0 = blockIdx.x * QPW;            // first query of the wave: always < q (grid is sized from q)
+    const int qi = q0 + lane / SUB;
+    const bool live = qi < q;
+    // dead lanes replicate the wave's first query so they do not inflate the query box
+    const float *qp = query + ((size_t)b * q + (live ? qi : q0)) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float qn = mcp_sqnorm3(qx, qy, qz);
+    ref += (size_t)b * n * 3;
+    rperm += (size_t)b * n;
+    boxes += (size_t)b * tiles * 6;
+
+    const float bl0 = wave_minf(qx), bl1 = wave_minf(qy), bl2 = wave_minf(qz);
+    const float bh0 = wave_maxf(qx), bh1 = wave_maxf(qy), bh2 = wave_maxf(qz);
+
+    // lower bound of the squared distance to each tile box; lane l owns tiles l, l+64, ...
+    float lb[MAX_TPL];
+    float m2 = fmaxf(fmaxf(fabsf(bl0), fabsf(bh0)), fmaxf(fmaxf(fabsf(bl1), fabsf(bh1)), fmaxf(fabsf(bl2), fabsf(bh2))));
+#pragma unroll
+    for (int u = 0; u < MAX_TPL; ++u) {
+        const int t = lane + 64 * u;
+        lb[u] = INFINITY;
+        if (t < tiles) {
+            const float *bx = boxes + t * 6;
+            const float g0 = fmaxf(0.f, fmaxf(bx[0] - bh0, bl0 - bx[3]));
+            const float g1 = fmaxf(0.f, fmaxf(bx[1] - bh1, bl1 - bx[4]));
+            const float g2 = fmaxf(0.f, fmaxf(bx[2] - bh2, bl2 - bx[5]));
+            lb[u] = g0 * g0 + g1 * g1 + g2 * g2;
+            m2 = fmaxf(m2, fmaxf(fmaxf(fabsf(bx[0]), fabsf(bx[3])), fmaxf(fmaxf(fabsf(bx[1]), fabsf(bx[4])), fmaxf(fabsf(bx[2]), fabsf(bx[5])))));
+        }
+    }
+    m2 = wave_maxf(m2);
+    // |computed - exact| of either distance form is below ~40 * 2^-24 * M^2 = 2.4e-6 M^2 (M = largest |coordinate|);
+    // the bound arithmetic errs by a few ulp of the bound: 3e-5*M^2 absolute + 1e-6 relative covers both.
+    const float slack_abs = 3e-5f * m2 * m2, slack_rel = 1e-6f;
+
+    u64 a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = KEY_INF;
+    float tau_own = live ? INFINITY : -INFINITY;  // dead lanes never push and never hold the wave back
+    float tau = tau_own;                          // shared push threshold of the query's SUB lanes
+    int cnt = 0;
+    auto flush = [&]() {
+        u64 qk[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const uint2 e = queue[s][lane];
+            qk[s] = s < cnt ? (((u64)mcp_ord(__uint_as_float(e.x)) << 32) | e.y) : KEY_INF;
+        }
+        bitonic_sort<QS>(qk);
+        merge_sorted<K, QS>(a, qk);
+        if (live) tau_own = tau_of(a[K - 1]);
+        tau = sub_min<SUB>(tau_own);
+        cnt = 0;
+    };
+
+    for (;;) {
+        // next tile: smallest remaining bound (ties -> lowest tile id)
+        float mylb = lb[0];
+        int myu = 0;
+#pragma unroll
+        for (int u = 1; u < MAX_TPL; ++u) {
+            if (lb[u] < mylb) { mylb = lb[u]; myu = u; }
+        }
+        const uint32_t key_hi = ~mcp_ord(mylb);                      // max-reduce of the inverted key = min bound
+        const uint32_t whi = mcp_wave_max_u32(key_hi);
+        const uint32_t myt = (uint32_t)(lane + 64 * myu);
+        const uint32_t wlo = mcp_wave_max_u32(key_hi == whi ? ~myt : 0u);
+        const float minlb = mcp_unord(~whi);
+        const int t = (int)(~wlo);
+        const float taumax = mcp_unord(mcp_wave_max_u32(mcp_ord(tau)));
+        if (minlb == INFINITY) break;  // every tile visited
+        if (!(minlb <= taumax + (taumax * slack_rel + slack_abs))) break;
+        if ((int)myt == t) {
+#pragma unroll
+            for (int u = 0; u < MAX_TPL; ++u)
+                if (u == myu) lb[u] = INFINITY;
+        }
+        // stage the tile: coordinates + squared norm in reference order, original indices grouped per sub-lane
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < PT / 64; ++u) {
+            const int r = lane + 64 * u, gi = t * PT + r;
+            float4 v;
+            int pi = 0;
+            if (gi < n) {
+                const float x = ref[(size_t)gi * 3 + 0], y = ref[(size_t)gi * 3 + 1], z = ref[(size_t)gi * 3 + 2];
+                v = make_float4(x, y, z, mcp_sqnorm3(x, y, z));
+                pi = rperm[gi];
+            } else {
+                v = MODE == MCP_DIST_EXPANSION ? make_float4(0.f, 0.f, 0.f, INFINITY) : make_float4(INFINITY, 0.f, 0.f, 0.f);
+            }
+            tile[r] = v;
+            tperm[(r % SUB) * RPL + r / SUB] = pi;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // lane scans references sub, sub+SUB, ... ; j-th reference of the lane is tile[j*SUB + sub]
+        const int4 *myperm = reinterpret_cast<const int4 *>(tperm + sub * RPL);
+        float4 rc[CHK];
+        int4 pc = myperm[0];
+#pragma unroll
+        for (int u = 0; u < CHK; ++u) rc[u] = tile[u * SUB + sub];
+        for (int j0 = 0; j0 < RPL; j0 += CHK) {
+            float4 rn[CHK];
+            const int jn = j0 + CHK < RPL ? j0 + CHK : j0;
+#pragma unroll
+            for (int u = 0; u < CHK; ++u) rn[u] = tile[(jn + u) * SUB + sub];
+            const int4 pn = myperm[jn >> 2];
+            float d[CHK];
+#pragma unroll
+            for (int u = 0; u < CHK; ++u) d[u] = pair_dist<MODE>(qx, qy, qz, qn, rc[u]);
+            const int pidx[CHK] = {pc.x, pc.y, pc.z, pc.w};
+#pragma unroll
+            for (int u = 0; u < CHK; ++u) {
+                if (d[u] <= tau) {
+                    queue[cnt][lane] = make_uint2(__float_as_uint(d[u]), (uint32_t)pidx[u]);
+                    ++cnt;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(cnt > QS - CHK)) flush();
+#pragma unroll
+            for (int u = 0; u < CHK; ++u) rc[u] = rn[u];
+            pc = pn;
+        }
+        // tighten tau before the next pruning decision, but only when a queue is at least half full: a stale
+        // (larger) tau is still a valid bound, it just prunes a little less
+        if (__builtin_amdgcn_ballot_w64(cnt >= QS / 2)) flush();
+    }
+    flush();
+    // merge the SUB lists of each query (after each round both partners hold the union's K smallest)
+    if (SUB >= 2) {
+        u64 o[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            o[j] = ((u64)mcp_dpp<0xB1>((uint32_t)(a[j] >> 32)) << 32) | mcp_dpp<0xB1>((uint32_t)a[j]);
+        merge_sorted<K, K>(a, o);
+    }
+    if (SUB >= 4) {
+        u64 o[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            o[j] = ((u64)mcp_dpp<0x4E>((uint32_t)(a[j] >> 32)) << 32) | mcp_dpp<0x4E>((uint32_t)a[j]);
+        merge_sorted<K, K>(a, o);
+    }
+    if (!live || sub != 0) return;
+    const int row = qperm ? qperm[(size_t)b * q + qi] : qi;
+    int *oi = idx + ((size_t)b * q + row) * kout;
+    float *od = dist ? dist + ((size_t)b * q + row) * kout : nullptr;
+    u64 last = a[0];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < kout) {
+            const u64 kk = a[j] == KEY_INF ? last : a[j];
+            last = kk;
+            oi[j] = kk == KEY_INF ? 0 : (int)(uint32_t)kk;
+            if (od) od[j] = kk == KEY_INF ? 0.f : mcp_unord((uint32_t)(kk >> 32));
+        }
+    }
+}
+
+template <int K, int MODE, int SUB>
+int launch_pruned_sub(int b, int q, int n, int tiles, int k, const float *query, const int *qperm, const float *ref, const int *rperm,
+                      const float *boxes, int *idx, float *dist, hipStream_t s) {
+    const size_t lds = (size_t)PrunedLds<K>::WAVE_BYTES;
+    auto kern = knn_pruned_kernel<K, MODE, SUB>;
+    static bool attr_done = false;
+    if (!attr_done) {  // lets the CU's whole 160 KB LDS count towards residency (default budget: 64 KB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 64 / SUB), b), dim3(64), lds, s, q, n, tiles, k, query, qperm,
+                       ref, rperm, boxes, idx, dist);
+    return mcp_launch_status();
+}
+
+int pruned_sub_lanes() {
+    // lanes per query: 4 by default (tuning hook: MCP_KNN_SUB=1|2|4)
+    static int sub = [] {
+        const char *e = getenv("MCP_KNN_SUB");
+        const int v = e ? atoi(e) : 4;
+        return (v == 1 || v == 2 || v == 4) ? v : 4;
+    }();
+    return sub;
+}
+
+template <int K, int MODE>
+int launch_pruned(int b, int q, int n, int tiles, int k, const float *query, const int *qperm, const float *ref, const int *rperm,
+                  const float *boxes, int *idx, float *dist, hipStream_t s) {
+    switch (pruned_sub_lanes()) {
+        case 1: return launch_pruned_sub<K, MODE, 1>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+        case 2: return launch_pruned_sub<K, MODE, 2>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+        default: return launch_pruned_sub<K, MODE, 4>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+    }
+}
+
+}  // namespace
+
+MCP_EXPORT int mcp_morton_codes(int b, int n, const float *xyz, const float *box, int *codes, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && box && codes);
+    hipLaunchKernelGGL(morton_kernel, dim3(mcp_divup(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, xyz, box, codes);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_tile_boxes(int b, int n, const float *sorted_xyz, float *boxes, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && sorted_xyz && boxes);
+    const int tiles = (n + PT - 1) / PT;
+    hipLaunchKernelGGL(tile_box_kernel, dim3(tiles, b), dim3(64), 0, (hipStream_t)stream, n, tiles, sorted_xyz, boxes);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_build_cloud(int b, int n, const float *xyz, float *sorted_xyz, int *perm, float *boxes, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && sorted_xyz && perm && boxes);
+    if (n > 16384) return MCP_ERR_UNSUPPORTED;  // larger clouds: mcp_morton_codes + an external sort + mcp_tile_boxes
+    int npow2 = 1;
+    while (npow2 < n) npow2 <<= 1;
+    const int tiles = (n + PT - 1) / PT;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(build_cloud_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(build_cloud_kernel, dim3(b), dim3(BT), (size_t)npow2 * 8 + 512, (hipStream_t)stream, n, npow2, tiles, xyz, sorted_xyz,
+                       perm, boxes);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_knn_pruned(int b, int q, int n, int k, int dist_form, const float *query_sorted, const int *qperm,
+                              const float *ref_sorted, const int *rperm, const float *boxes, int *idx, float *dist,
+                              mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && q > 0 && n > 0 && k > 0 && query_sorted && ref_sorted && rperm && boxes && idx);
+    MCP_CHECK_ARGS(dist_form == MCP_DIST_EXPANSION || dist_form == MCP_DIST_DIRECT);
+    const int tiles = (n + PT - 1) / PT;
+    if (k > 32 || k <= 4 || tiles > 64 * MAX_TPL) return MCP_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    mcp_prof_begin(MCP_KERNEL_KNN, s);
+    int rc;
+    if (dist_form == MCP_DIST_EXPANSION)
+        rc = k <= 16 ? launch_pruned<16, MCP_DIST_EXPANSION>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s)
+                     : launch_pruned<32, MCP_DIST_EXPANSION>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s);
+    else
+        rc = k <= 16 ? launch_pruned<16, MCP_DIST_DIRECT>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s)
+                     : launch_pruned<32, MCP_DIST_DIRECT>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s);
+    mcp_prof_end(MCP_KERNEL_KNN, s);
+    return rc;
+}

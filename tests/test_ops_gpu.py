@@ -235,3 +235,34 @@ def test_compat_helpers_keep_reference_signatures():
     d, i, _ = compat.knn_points(new_xyz, xyz, K=4)
     wi, wd = orc.knn(new_xyz.cpu(), xyz.cpu(), 4, mode=1, return_dist=True)
     assert torch.equal(i.cpu().int(), wi) and torch.equal(d.cpu(), wd)
+
+
+@pytest.mark.parametrize("q,n,k,mode,b", [(8192, 8192, 32, 0, 2), (2048, 8192, 32, 0, 2), (4096, 5000, 16, 1, 2), (1500, 16384, 32, 0, 1),
+                                          (8192, 8192, 7, 1, 1), (1024, 65536, 32, 0, 1)])
+def test_knn_pruned_equals_bruteforce_and_oracle(q, n, k, mode, b):
+    """The Morton/box-pruned search must return exactly what the exhaustive scan returns."""
+    be = ops.backend()
+    ref = cloud(131 + n, b, n)
+    query = ref if q == n else cloud(132 + q, b, q)
+    rd, qd = ref.to(DEV), (None if q == n else query.to(DEV))
+    qd = rd if qd is None else qd
+    gi_, gd = be.knn(qd, rd, k, mode=mode, return_dist=True)           # pruned path (n >= 4096, q >= 1024)
+    bi, bd = be.knn_bruteforce(qd, rd, k, mode=mode, return_dist=True)
+    assert torch.equal(gi_, bi) and torch.equal(gd, bd)
+    if n <= 16384:
+        wi, wd = orc.knn(query, ref, k, mode=mode, return_dist=True)
+        assert torch.equal(gi_.cpu(), wi) and torch.equal(gd.cpu(), wd)
+
+
+def test_knn_pruned_clustered_and_degenerate_clouds():
+    be = ops.backend()
+    g = torch.Generator().manual_seed(5)
+    # two tight clusters far apart + a flat (z = const) cloud + all points identical
+    a = torch.cat([torch.randn(1, 3000, 3, generator=g) * 0.01, torch.randn(1, 3000, 3, generator=g) * 0.01 + 500.0], 1)
+    flat = torch.rand(1, 6000, 3, generator=g) * torch.tensor([100.0, 100.0, 0.0])
+    same = torch.ones(1, 5000, 3) * 3.25
+    for c in (a, flat, same):
+        x = c.contiguous().to(DEV)
+        i1, d1 = be.knn(x, x, 32, return_dist=True)
+        i2, d2 = be.knn_bruteforce(x, x, 32, return_dist=True)
+        assert torch.equal(i1, i2) and torch.equal(d1, d2)
