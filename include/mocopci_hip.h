@@ -165,6 +165,14 @@ int mcp_pointconv_agg(int b, int n, int s, int d, int k, const float *s_xyz, con
                       const int *idx, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                       const float *b2, float *out, mcp_stream_t stream);
 
+/* Multi-head attention with a tiny head dim (8 or 16) in exact fp32, flash style (no (N,N) score tensor):
+ * the attention core of InterFrameAttentionInterpretation (mocopci.py:650-667) and CrossAttention (:72-86).
+ * q (BF,Nq,*), k/v (BF,Nk,*) are read in place from the projection outputs: element [bf, token, head*hd + d]
+ * at ptr + (bf*N + token)*stride + head*hd + d (strides in floats, multiples of 4; pointers 16-byte aligned);
+ * out (BF,Nq,*) likewise.  softmax(q.k^T * scale) . v per (bf, head). */
+int mcp_attention_small(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
+                        const float *v, int v_stride, float scale, float *out, int out_stride, mcp_stream_t stream);
+
 /* chamfer_loss (models/utils.py:36-45 -> pytorch3d chamfer_distance defaults): per-point squared
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
@@ -181,6 +189,7 @@ int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *d
 #define MCP_KERNEL_FUSION 6
 #define MCP_KERNEL_CROSS 7
 #define MCP_KERNEL_POINTCONV 8
+#define MCP_KERNEL_ATTENTION 9
 int mcp_prof_enable(int kernel_id); /* 0 disables */
 int mcp_prof_collect(int *launches, float *total_ms);
 

@@ -215,11 +215,8 @@ class MoCoPCI(nn.Module):
     # ---- dense blocks (callers; PyTorch dense ops) ---------------------------------------
     def cross_attention(self, prefix, x, c, heads=8):
         """CrossAttention.forward (mocopci.py:72-86)."""
-        B, N, C = x.shape
-        kv = self.lin(c, prefix + ".kv").reshape(B, N, 2, heads, C // heads).permute(2, 0, 3, 1, 4)
-        q = self.lin(x, prefix + ".q").reshape(B, N, heads, C // heads).permute(0, 2, 1, 3)
-        o = F.scaled_dot_product_attention(q, kv[0], kv[1])
-        return self.lin(o.transpose(1, 2).reshape(B, N, C), prefix + ".proj")
+        o = ops.backend().attention(self.lin(x, prefix + ".q"), self.lin(c, prefix + ".kv"), heads)
+        return self.lin(o, prefix + ".proj")
 
     def layer_norm(self, x, name):
         P = self._params()
@@ -268,11 +265,9 @@ class MoCoPCI(nn.Module):
         xr = torch.flip(xn, dims=[1])
         a = prefix + ".attn_feats"
         hd = C // heads
-        # 4-D (batch*frames, heads, N, hd) so SDPA can pick a fused kernel instead of the math path
-        q = self.lin(xn, a + ".q").reshape(B * Fr, N, heads, hd).permute(0, 2, 1, 3)
-        kv = self.lin(xr, a + ".kv").reshape(B * Fr, N, 2, heads, hd).permute(2, 0, 3, 1, 4)
-        o = F.scaled_dot_product_attention(q, kv[0], kv[1])                       # (B*5,H,N,hd)
-        o = self.lin(o.permute(0, 2, 1, 3).reshape(B, Fr, N, C), a + ".proj")
+        o = ops.backend().attention(self.lin(xn, a + ".q").reshape(B * Fr, N, C), self.lin(xr, a + ".kv").reshape(B * Fr, N, 2 * C),
+                                    heads)                                         # (B*5,N,C)
+        o = self.lin(o.reshape(B, Fr, N, C), a + ".proj")
         xn = xn + o
         xb = self.mlp_t(prefix + ".mlp", self.bn_eval(xn, prefix + ".norm2", 1e-5))
         x = x + xb

@@ -179,6 +179,26 @@ class HipBackend:
               _lib.iptr(idx), _lib.fptr(w0), _lib.fptr(b0), _lib.fptr(w1), _lib.fptr(b1), _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(out))
         return out
 
+    def attention(self, q, kv, heads, scale=None):
+        """softmax(q k^T * scale) v per head, reading the projection outputs in place: q (BF,Nq,C), kv (BF,Nk,2C)
+        laid out [k | v] as the reference's kv Linear produces (mocopci.py:74-75, :653-654) -> (BF,Nq,C)."""
+        BF, Nq, C = q.shape
+        Nk = kv.shape[1]
+        hd = C // heads
+        if scale is None:
+            scale = hd ** -0.5
+        if hd in (8, 16):
+            _lib.fptr(q), _lib.fptr(kv)
+            out = torch.empty((BF, Nq, C), dtype=torch.float32, device=q.device)
+            _call("mcp_attention_small", q, BF, Nq, Nk, heads, hd, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
+                  float(scale), out.data_ptr(), C)
+            return out
+        # larger head dims (ei3: 32, cross-frame block: 256) are ordinary dense attention: library kernel
+        qh = q.reshape(BF, Nq, heads, hd).permute(0, 2, 1, 3)
+        kvh = kv.reshape(BF, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+        o = torch.nn.functional.scaled_dot_product_attention(qh, kvh[0], kvh[1], scale=scale)
+        return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
+
     def chamfer(self, x, y):
         """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor."""
         B, N, _ = x.shape
@@ -204,7 +224,7 @@ def set_backend(b):
 
 
 # ---- instrumentation passthrough (bench.py) ----
-KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7, "pointconv": 8}
+KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7, "pointconv": 8, "attention": 9}
 
 
 def prof_enable(kernel_name):

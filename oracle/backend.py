@@ -71,5 +71,14 @@ class OracleBackend:
             w = torch.relu(F.linear(w, ww, bb))
         return torch.matmul(new_points.transpose(2, 3), w).reshape(B, S, -1)
 
+    def attention(self, q, kv, heads, scale=None):
+        BF, Nq, C = q.shape
+        Nk = kv.shape[1]
+        hd = C // heads
+        qh = q.reshape(BF, Nq, heads, hd).permute(0, 2, 1, 3)
+        kvh = kv.reshape(BF, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+        o = torch.nn.functional.scaled_dot_product_attention(qh, kvh[0], kvh[1], scale=scale)
+        return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
+
     def chamfer(self, x, y):
         return torch.tensor(orc.chamfer(x, y), dtype=torch.float32)

@@ -266,3 +266,15 @@ def test_knn_pruned_clustered_and_degenerate_clouds():
         i1, d1 = be.knn(x, x, 32, return_dist=True)
         i2, d2 = be.knn_bruteforce(x, x, 32, return_dist=True)
         assert torch.equal(i1, i2) and torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize("bf,nq,nk,heads,hd", [(4, 2048, 2048, 8, 8), (6, 512, 512, 8, 16), (2, 300, 777, 4, 8), (1, 33, 70, 2, 16)])
+def test_attention_small_matches_fp32_reference(bf, nq, nk, heads, hd):
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(nq + hd)
+    C = heads * hd
+    q = torch.randn(bf, nq, C, generator=g)
+    kv = torch.randn(bf, nk, 2 * C, generator=g)
+    want = OracleBackend().attention(q.double(), kv.double(), heads).float()   # float64 reference
+    got = ops.backend().attention(q.to(DEV), kv.to(DEV), heads).cpu()
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
