@@ -12,8 +12,9 @@ Multi-GPU: sequences shard across ranks with no data-path collective; the only e
 all_gather of the output frames over RCCL (inside the timed step).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel, timed live with hipEvents around each launch on the
-               launch stream inside the timed region; achieved = algorithmic bytes / kernel time
+  roofline     dominant hand-written kernel by time (FPS / KNN / fusion are all timed live with hipEvents around each
+               launch on its launch stream inside the timed region); achieved = algorithmic bytes or flops per launch
+               / average launch duration; roofline_others holds the same figures for the other timed kernels
   cpu_baseline the same graph on the CPU oracle backend (oracle/, "port") for ONE sequence, rank 0, N=1 only
 """
 import argparse
@@ -28,15 +29,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA spec (155 measured)
 NPOINTS = 8192
 B_PER_GPU = 8
-DOMINANT = "knn"
+TIMED_KERNELS = ("fps", "knn", "fusion")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 
 
-def knn_algorithmic_bytes(calls):
-    """compulsory bytes of a KNN search = B*(12Q + 12N + 4QK)."""
-    return sum(b * (12 * q + 12 * n + 4 * q * k) for (b, q, n, k) in calls)
+def algorithmic_work(kernel, calls):
+    """SURVEY.md 8(d) per-unit figures x the units each launch processes (shapes logged from one untimed step).
+    fps:    B*(M-1)*20*N bytes -- the reference's streaming formulation (12 B xyz + 4 B temp read + 4 B temp write per
+            point per iteration, sampling_gpu.cu:118-141); the resident kernel's compulsory traffic is B*(16N+4M).
+    knn:    compulsory bytes B*(12Q + 12N + 4QK) per search (3-NN searches inside interp3 included).
+    fusion: flops, 2*64 neighbours*(4*64 + 64*64 + 64*128) MACs per point (mocopci.py:749-755)."""
+    if kernel == "fps":
+        return sum(b * (m - 1) * 20 * n for (b, n, m) in calls), "bytes"
+    if kernel == "knn":
+        return sum(b * (12 * q + 12 * n + 4 * q * k) for (b, q, n, k) in calls), "bytes"
+    if kernel == "fusion":
+        return sum(b * n * 2 * 64 * (4 * 64 + 64 * 64 + 64 * 128) for (b, n) in calls), "flops"
+    raise KeyError(kernel)
 
 
 def main():
@@ -75,21 +88,27 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    # record KNN call shapes once (outside the timed region) for the algorithmic-byte count
-    knn_calls = []
+    # log call shapes of the timed kernels once (outside the timed region) for the algorithmic-work count
+    calls = {k: [] for k in TIMED_KERNELS}
     be = ops.backend()
-    orig_knn = be.knn
+    orig = {n: getattr(be, n) for n in ("fps", "knn", "interp3", "interp3_search", "fusion_mlp")}
 
-    def logged_knn(query, ref, k, mode=0, return_dist=False):
-        knn_calls.append((query.shape[0], query.shape[1], ref.shape[1], 3 if k == 3 else k))
-        return orig_knn(query, ref, k, mode=mode, return_dist=return_dist)
+    def wrap(name, rec):
+        def f(*a, **k):
+            rec(*a, **k)
+            return orig[name](*a, **k)
+        return f
 
-    be.knn = logged_knn
+    be.fps = wrap("fps", lambda xyz, m: calls["fps"].append((xyz.shape[0], xyz.shape[1], m)))
+    be.knn = wrap("knn", lambda q, r, k, **kw: calls["knn"].append((q.shape[0], q.shape[1], r.shape[1], k)))
+    be.interp3 = wrap("interp3", lambda d, s_, f: calls["knn"].append((d.shape[0], d.shape[1], s_.shape[1], 3)))
+    be.interp3_search = wrap("interp3_search", lambda d, s_: calls["knn"].append((d.shape[0], d.shape[1], s_.shape[1], 3)))
+    be.fusion_mlp = wrap("fusion_mlp", lambda p1, *a: calls["fusion"].append((p1.shape[0], p1.shape[1])))
     step()
-    be.knn = orig_knn
-    knn_calls_per_step = list(knn_calls)
+    for n in orig:
+        delattr(be, n)  # back to the class methods
 
-    ops.prof_enable(DOMINANT)
+    ops.prof_enable(TIMED_KERNELS)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -100,7 +119,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    launches, kernel_ms = ops.prof_collect()
+    timed = {k: ops.prof_collect(k) for k in TIMED_KERNELS}
     ops.prof_enable(None)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -131,16 +150,33 @@ def main():
                    "weights": "deterministic by-name synthetic, eval mode"},
         "chamfer_vs_gt": chamfer,
     }
-    # launches of the dominant kernel inside the timed region (interp3's internal 3-NN searches are
-    # timed as part of the same kernel id)
-    alg_bytes = knn_algorithmic_bytes(knn_calls_per_step) * args.steps
-    if launches and kernel_ms > 0:
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        result["roofline"] = {"kernel": "mcp_knn (knn_queue_kernel / knn_small_kernel)", "bound": "hbm", "achieved": achieved,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                              "launches": launches, "avg_launch_us": 1000.0 * kernel_ms / launches,
-                              "kernel_ms_per_step": kernel_ms / args.steps,
-                              "note": "algorithmic = compulsory bytes B*(12Q+12N+4QK) per search (SURVEY 8d); the search is VALU/LDS-bound once the distance matrix is gone"}
+    # roofline of the hand-written kernels timed live (hipEvents on their launch streams, inside the timed region)
+    pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}
+    entries = []
+    names = {"fps": "fps_resident_kernel (mcp_furthest_point_sampling)", "knn": "knn_pruned/knn_queue/knn_small kernels (mcp_knn*)",
+             "fusion": "fusion_kernel (mcp_fusion)"}
+    notes = {"fps": "algorithmic = reference streaming formulation B*(M-1)*20*N (SURVEY 8d); the kernel keeps points and temp in VGPRs, "
+                    "so real HBM traffic is the compulsory B*(16N+4M); it is latency-bound on M-1 dependent iterations, one workgroup per batch element",
+             "knn": "algorithmic = compulsory bytes B*(12Q+12N+4QK) per search (SURVEY 8d); with the distance matrix gone the search is VALU-bound, not HBM-bound",
+             "fusion": "fp32 MFMA chain 4->64->64->128 per neighbour; 392 v_mfma_f32_32x32x2_f32 per point"}
+    for kname in TIMED_KERNELS:
+        launches, kms = timed[kname]
+        if not launches or kms <= 0:
+            continue
+        work, unit = algorithmic_work(kname, calls[kname])
+        per_launch = work * args.steps / launches
+        avg_s = kms * 1e-3 / launches
+        if unit == "bytes":
+            ach, peak, u, bound = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+        else:
+            ach, peak, u, bound = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", "mfma"
+        entries.append({"kernel": names[kname], "bound": bound, "achieved": ach, "peak": peak, "unit": u, "frac": ach / peak,
+                        "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"), "launches": launches,
+                        "avg_launch_us": 1e6 * avg_s, "kernel_ms_per_step": kms / args.steps, "note": notes[kname]})
+    entries.sort(key=lambda e: -e["kernel_ms_per_step"])
+    if entries:
+        result["roofline"] = entries[0]            # the dominant hand-written kernel by time in the step
+        result["roofline_others"] = entries[1:]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

@@ -178,9 +178,9 @@ int mcp_attention_small(int bf, int nq, int nk, int heads, int hd, const float *
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
 
 /* ---------------- Instrumentation (bench.py roofline leg) --------------------------- */
-/* When enabled for a kernel id, each launch of that kernel is bracketed by hipEvents on the launch
- * stream; mcp_prof_collect synchronises those events and returns launches and total milliseconds.
- * Off by default; not used on the product path. */
+/* mcp_prof_enable(mask): every launch of a kernel whose id bit (1 << MCP_KERNEL_*) is set in mask is bracketed
+ * by hipEvents recorded on the launch stream; mask 0 disables and clears.  mcp_prof_collect(id, ...) synchronises
+ * that kernel's events and returns its launch count and total milliseconds.  Off by default. */
 #define MCP_KERNEL_FPS 1
 #define MCP_KERNEL_KNN 2
 #define MCP_KERNEL_GROUP_ROWS 3
@@ -190,8 +190,8 @@ int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *d
 #define MCP_KERNEL_CROSS 7
 #define MCP_KERNEL_POINTCONV 8
 #define MCP_KERNEL_ATTENTION 9
-int mcp_prof_enable(int kernel_id); /* 0 disables */
-int mcp_prof_collect(int *launches, float *total_ms);
+int mcp_prof_enable(int kernel_mask);
+int mcp_prof_collect(int kernel_id, int *launches, float *total_ms);
 
 #ifdef __cplusplus
 }

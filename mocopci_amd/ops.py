@@ -227,12 +227,16 @@ def set_backend(b):
 KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7, "pointconv": 8, "attention": 9}
 
 
-def prof_enable(kernel_name):
-    _lib.check(_lib.load().mcp_prof_enable(KERNEL_IDS.get(kernel_name, 0) if kernel_name else 0))
+def prof_enable(kernel_names):
+    """Time every launch of the named kernels (iterable of KERNEL_IDS keys) with hipEvents; None/() disables."""
+    mask = 0
+    for name in (kernel_names or ()):
+        mask |= 1 << KERNEL_IDS[name]
+    _lib.check(_lib.load().mcp_prof_enable(mask))
 
 
-def prof_collect():
+def prof_collect(kernel_name):
     n = ctypes.c_int(0)
     ms = ctypes.c_float(0.0)
-    _lib.check(_lib.load().mcp_prof_collect(ctypes.byref(n), ctypes.byref(ms)))
+    _lib.check(_lib.load().mcp_prof_collect(KERNEL_IDS[kernel_name], ctypes.byref(n), ctypes.byref(ms)))
     return n.value, ms.value

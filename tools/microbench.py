@@ -14,6 +14,8 @@ f128 = torch.randn(16, 512, 128, device=dev); f128b = torch.randn(16, 512, 128, 
 idx32 = torch.randint(0, 2048, (16, 2048, 32), device=dev, dtype=torch.int32)
 idx64 = torch.randint(0, 8192, (24, 8192, 64), device=dev, dtype=torch.int32)
 w = lambda *s: torch.randn(*s, device=dev) * 0.1
+qa = torch.randn(80, 2048, 64, device=dev); kva = torch.randn(80, 2048, 128, device=dev)
+qb = torch.randn(80, 512, 128, device=dev); kvb = torch.randn(80, 512, 256, device=dev)
 cases = {
     "fps 16x8192->2048": lambda: be.fps(xyz16, 2048),
     "fps 24x8192->2048": lambda: be.fps(xyz24, 2048),
@@ -27,6 +29,9 @@ cases = {
     "knn_cosine 16x512 c128": lambda: be.knn_cosine(f128, f128b, 16),
     "cross 16x2048 d64": lambda: be.cross_volume(q2048, q2048, f64, f64b, idx32, w(64, 3), w(64), w(64, 64), w(64)),
     "fusion 24x8192": lambda: be.fusion_mlp(xyz24, xyz24, idx64, w(64, 4), w(64), w(64, 64), w(64), w(128, 64), w(128)),
+    "attention 80x8h x2048 hd8": lambda: be.attention(qa, kva, 8),
+    "attention 80x8h x512 hd16": lambda: be.attention(qb, kvb, 8),
+    "attention 8x8h x2048 hd8": lambda: be.attention(qa[:8].contiguous(), kva[:8].contiguous(), 8),
     "pointconv_agg 16x8192 d32": lambda: be.pointconv_agg(xyz16, xyz16, torch.randn(16, 8192, 32, device=dev), idx64[:16, :, :32].contiguous(), w(8, 3), w(8), w(8, 8), w(8), w(8, 8), w(8)),
 }
 only = sys.argv[1:] 
