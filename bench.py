@@ -129,6 +129,9 @@ def main():
     # quality: Chamfer of each interpolated frame vs the synthetic GT (local shard)
     local = frames[rank * B_PER_GPU:(rank + 1) * B_PER_GPU]
     chamfer = [float(ops.backend().chamfer(local[:, j].contiguous(), gt[j])) for j in range(3)]
+    # second metric of test.py:90 (approximate EMD, per-point normalised as models/utils.py:223-235), outside the timed region
+    from mocopci_amd import emd as emd_mod
+    emd = [float(emd_mod.EMD(local[:, j].permute(0, 2, 1).contiguous(), gt[j].permute(0, 2, 1).contiguous())) for j in range(3)]
 
     total_frames = 3 * B_PER_GPU * world * args.steps
     result = {
@@ -149,6 +152,7 @@ def main():
                    "parallelism": f"sequence-sharded x{world}, final all_gather over RCCL" if world > 1 else "single GPU",
                    "weights": "deterministic by-name synthetic, eval mode"},
         "chamfer_vs_gt": chamfer,
+        "emd_vs_gt": emd,
     }
     # roofline of the hand-written kernels timed live (hipEvents on their launch streams, inside the timed region)
     pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}

@@ -177,6 +177,13 @@ int mcp_attention_small(int bf, int nq, int nk, int heads, int hd, const float *
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
 
+/* Approximate Earth Mover's Distance (metric of test.py:90): approxmatch + matchcost of
+ * models/EMD/cuda/emd_kernel.cu:29-162, :204-247 (emd_cuda.approxmatch_forward / matchcost_forward, emd.py:11-12).
+ * xyz1 (B,N,3), xyz2 (B,M,3) -> cost (B) = sum_{l,k} match[l][k] |xyz2[l]-xyz1[k]|^2.  match (B,M,N) is written
+ * only if non-NULL (the cost is accumulated while the transfers are produced).  workspace: B*(3N+2M) floats. */
+int mcp_emd(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *cost, float *workspace,
+            mcp_stream_t stream);
+
 /* ---------------- Instrumentation (bench.py roofline leg) --------------------------- */
 /* mcp_prof_enable(mask): every launch of a kernel whose id bit (1 << MCP_KERNEL_*) is set in mask is bracketed
  * by hipEvents recorded on the launch stream; mask 0 disables and clears.  mcp_prof_collect(id, ...) synchronises

@@ -40,6 +40,7 @@ SIGNATURES = {
     "mcp_pointconv_agg": [_i] * 5 + [_p] * 12,
     "mcp_attention_small": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
     "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_emd": [_i, _i, _i, _p, _p, _p, _p, _p, _p],
     "mcp_prof_enable": [_i],
     "mcp_prof_collect": [_i, _p, _p],
 }

@@ -179,3 +179,19 @@ def chamfer(x, y):
     B, N, _ = x.shape
     M = y.shape[1]
     return float(lib().orc_chamfer(_f(x.contiguous()), _f(y.contiguous()), B, N, M))
+
+
+def earth_mover_distance(xyz1, xyz2, return_match=False):
+    """models/EMD/emd.py:26-45 with transpose=False: xyz1 (B,N,3), xyz2 (B,M,3) -> cost (B)."""
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    match = torch.empty(B, M, N, dtype=torch.float32)
+    cost = torch.empty(B, dtype=torch.float32)
+    lib().orc_emd(_f(xyz1.contiguous()), _f(xyz2.contiguous()), _f(match), _f(cost), B, N, M)
+    return (cost, match) if return_match else cost
+
+
+def EMD(pc1, pc2):
+    """models/utils.py:223-235: pc (B,3,N) -> mean(cost)/N."""
+    d = earth_mover_distance(pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous())
+    return torch.mean(d) / pc1.shape[2]

@@ -403,3 +403,63 @@ ORC_API double orc_chamfer(const float *x, const float *y, int b, int n, int m) 
     }
     return total / b;
 }
+
+/* ------------------------------------------------------------------------
+ * EMD metric: approxmatch + matchcost,
+ * models/EMD/cuda/emd_kernel.cu:29-162 and :204-247 (Fan et al. soft auction, 10 levels
+ * j = 7..-2, level = -4^j, last level 0).  Sequential restatement of one block's work:
+ * same pass order, same per-thread summation order (l ascending / k ascending), expf in
+ * place of the device's __expf.  match is (B, m, n) as in the reference; temp is internal.
+ * Returns cost (B) = sum_{l,k} match[l][k] * |xyz2[l]-xyz1[k]|^2.
+ * ------------------------------------------------------------------------ */
+static inline float emd_d2(const float *a, const float *b) {
+    /* (x2-x1)*(x2-x1)+(y2-y1)*(y2-y1)+(z2-z1)*(z2-z1): canon fma(dz,dz, fma(dy,dy, dx*dx)) */
+    return sqdist3(b[0], b[1], b[2], a[0], a[1], a[2]);
+}
+
+ORC_API int orc_emd(const float *xyz1, const float *xyz2, float *match, float *cost, int b, int n, int m) {
+    float *remainL = (float *)malloc(sizeof(float) * (size_t)(n + m) * 2);
+    float *remainR = remainL + n, *ratioL = remainL + n + m, *ratioR = remainL + n + m + n;
+    float multiL, multiR;
+    if (n >= m) { multiL = 1; multiR = (float)(n / m); } else { multiL = (float)(m / n); multiR = 1; }
+    for (int i = 0; i < b; ++i) {
+        const float *p1 = xyz1 + (size_t)i * n * 3, *p2 = xyz2 + (size_t)i * m * 3;
+        float *mt = match + (size_t)i * n * m;
+        for (size_t j = 0; j < (size_t)n * m; ++j) mt[j] = 0;
+        for (int j = 0; j < n; ++j) remainL[j] = multiL;
+        for (int j = 0; j < m; ++j) remainR[j] = multiR;
+        for (int j = 7; j >= -2; --j) {
+            float level = -powf(4.0f, (float)j);
+            if (j == -2) level = 0;
+            for (int k = 0; k < n; ++k) {
+                float suml = 1e-9f;
+                for (int l = 0; l < m; ++l) suml += expf(level * emd_d2(p1 + k * 3, p2 + l * 3)) * remainR[l];
+                ratioL[k] = remainL[k] / suml;
+            }
+            for (int l = 0; l < m; ++l) {
+                float sumr = 0;
+                for (int k = 0; k < n; ++k) sumr += expf(level * emd_d2(p1 + k * 3, p2 + l * 3)) * ratioL[k];
+                sumr *= remainR[l];
+                float consumption = fminf(remainR[l] / (sumr + 1e-9f), 1.0f);
+                ratioR[l] = consumption * remainR[l];
+                remainR[l] = fmaxf(0.0f, remainR[l] - sumr);
+            }
+            for (int k = 0; k < n; ++k) {
+                float suml = 0, rl = ratioL[k];
+                for (int l = 0; l < m; ++l) {
+                    float w = expf(level * emd_d2(p1 + k * 3, p2 + l * 3)) * rl * ratioR[l];
+                    mt[(size_t)l * n + k] += w;
+                    suml += w;
+                }
+                remainL[k] = fmaxf(0.0f, remainL[k] - suml);
+            }
+        }
+        /* matchcost, emd_kernel.cu:204-247 (double accumulation here; the device sums in fp32) */
+        double s = 0.0;
+        for (int k = 0; k < n; ++k)
+            for (int l = 0; l < m; ++l) s += (double)emd_d2(p1 + k * 3, p2 + l * 3) * (double)mt[(size_t)l * n + k];
+        cost[i] = (float)s;
+    }
+    free(remainL);
+    return 0;
+}
