@@ -100,16 +100,17 @@ int mcp_knn(int b, int q, int n, int k, int dist_form, const float *query, const
             mcp_stream_t stream);
 
 /* Spatially pruned variant of mcp_knn for large clouds: identical results (same definition, same fp32
- * canon), but queries and references are given in Morton order and each tile of 128 sorted references
+ * canon), but queries and references are given in Morton order and each tile of consecutive sorted references
  * has a bounding box, so a wave visits tiles by ascending lower bound and stops early.
  *   mcp_morton_codes: xyz (B,N,3), box (B,6) = per-batch (min xyz, max xyz) -> codes (B,N) int32 (30 bit);
  *                     the caller sorts by code (any stable or unstable sort) to get a permutation.
- *   mcp_tile_boxes:   sorted_xyz (B,N,3) -> boxes (B,ceil(N/128),6).
+ *   mcp_tile_boxes:   sorted_xyz (B,N,3) -> boxes (B,ceil(N/tile),6), tile = mcp_knn_tile_size().
  *   mcp_knn_pruned:   query_sorted (B,Q,3) with qperm (B,Q) = original row of each sorted query (NULL = identity),
  *                     ref_sorted (B,N,3) with rperm (B,N) = original index of each sorted reference, boxes as above
  *                     -> idx (B,Q,K) ORIGINAL reference indices at ORIGINAL query rows (+ dist).  4 < K <= 32, N <= 65536.
  *   mcp_build_cloud:  all of the above in one launch for N <= 16384 (bbox, isotropic Morton keys, in-LDS sort, gather,
- *                     tile boxes): xyz (B,N,3) -> sorted_xyz (B,N,3), perm (B,N) int32, boxes (B,ceil(N/128),6). */
+ *                     tile boxes): xyz (B,N,3) -> sorted_xyz (B,N,3), perm (B,N) int32, boxes (B,ceil(N/tile),6). */
+int mcp_knn_tile_size(void); /* references per box tile (64): boxes arrays have ceil(N / tile) rows */
 int mcp_build_cloud(int b, int n, const float *xyz, float *sorted_xyz, int *perm, float *boxes, mcp_stream_t stream);
 int mcp_morton_codes(int b, int n, const float *xyz, const float *box, int *codes, mcp_stream_t stream);
 int mcp_tile_boxes(int b, int n, const float *sorted_xyz, float *boxes, mcp_stream_t stream);

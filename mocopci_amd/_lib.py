@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmocopci_hip.so")
+# MCP_HIP_LIB overrides the library path (A/B runs of two builds on one device); default: the in-tree build
+SO_PATH = os.environ.get("MCP_HIP_LIB") or os.path.join(_HERE, "libmocopci_hip.so")
 
 _i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -27,6 +28,7 @@ SIGNATURES = {
     "mcp_three_interpolate": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_three_interpolate_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_knn": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_knn_tile_size": [],
     "mcp_build_cloud": [_i, _i, _p, _p, _p, _p, _p],
     "mcp_morton_codes": [_i, _i, _p, _p, _p, _p],
     "mcp_tile_boxes": [_i, _i, _p, _p, _p],

@@ -15,7 +15,7 @@
 //     knn.hip; candidates carry the ORIGINAL reference index (tie order is defined on it), and
 //     "d <= tau" (not "<") is used because tiles are no longer visited in index order;
 //   * results are written to the query's original row (qperm).
-// At N=8192 a wave scans ~1000 of the 8192 references.
+// At N=8192 a wave scans ~1300 of the 8192 references (64-point tiles measured 5-7 % faster than 128/256).
 #include <stdlib.h>
 
 #include "common.h"
@@ -24,8 +24,11 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr u64 KEY_INF = ~0ull;
-constexpr int PT = 128;      // references per tile
-constexpr int MAX_TPL = 8;   // tiles per lane -> up to 512 tiles (N <= 65536)
+#ifndef MCP_PRUNED_PT
+#define MCP_PRUNED_PT 64
+#endif
+constexpr int PT = MCP_PRUNED_PT;  // references per tile
+constexpr int MAX_TPL = 16;  // tiles per lane -> up to 1024 tiles (N <= 65536 at 64 references per tile)
 
 __device__ __forceinline__ void ce_asc(u64 &a, u64 &b) {
     const bool sw = b < a;
@@ -476,6 +479,8 @@ int launch_pruned(int b, int q, int n, int tiles, int k, const float *query, con
 }
 
 }  // namespace
+
+MCP_EXPORT int mcp_knn_tile_size(void) { return PT; }
 
 MCP_EXPORT int mcp_morton_codes(int b, int n, const float *xyz, const float *box, int *codes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && box && codes);

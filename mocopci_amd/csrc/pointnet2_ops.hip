@@ -80,37 +80,39 @@ __global__ __launch_bounds__(BLK) void group_rows_kernel(int n, int cv, long lon
     }
 }
 
-// K4  ball_query_gpu.cu:9-45.  Lane per centre; xyz streamed through an LDS tile; a wave stops
-// scanning once all of its lanes have nsample hits (the reference breaks per thread).
-constexpr int BQ_TILE = 1024;
-__global__ __launch_bounds__(BLK) void ball_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
-                                                         const float *__restrict__ xyz, int *__restrict__ idx) {
-    __shared__ float tile[BQ_TILE * 3];
+// K4  ball_query_gpu.cu:9-45.  The reference gives one thread per centre a serial scan of all N points with an
+// early break.  Here a WAVE owns a centre: lane l tests points 64*i + l (coalesced reads), the hit mask of each step
+// is a ballot, and a hit's output slot is (hits so far) + (hits in lower lanes) -- exactly the reference's index
+// order -- so the scan stops, wave-uniformly, as soon as nsample hits exist.  Slots beyond the hit count are filled
+// with the first hit (the reference writes it to every slot when it is found); centres with no hit keep the
+// caller's zeros.
+constexpr int BQ_WAVES = 4;
+__global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_kernel(int n, int m, float radius2, int nsample,
+                                                                   const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                                                                   int *__restrict__ idx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const int p = blockIdx.x * BLK + threadIdx.x;
-    const bool live = p < m;
-    const float *q = new_xyz + ((size_t)b * m + (live ? p : 0)) * 3;
+    const int p = blockIdx.x * BQ_WAVES + wave;
+    if (p >= m) return;  // whole wave; no barriers below
+    const float *q = new_xyz + ((size_t)b * m + p) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float *rb = xyz + (size_t)b * n * 3;
-    int *o = idx + ((size_t)b * m + (live ? p : 0)) * nsample;
-    int cnt = live ? 0 : nsample;
-    for (int base = 0; base < n; base += BQ_TILE) {
-        const int len = min(BQ_TILE, n - base);
-        __syncthreads();
-        for (int i = threadIdx.x; i < len * 3; i += BLK) tile[i] = rb[(size_t)base * 3 + i];
-        __syncthreads();
-        if (__syncthreads_and(cnt >= nsample)) break;
-        for (int k = 0; k < len; ++k) {
-            if (!__builtin_amdgcn_ballot_w64(cnt < nsample)) break;
-            const float d2 = mcp_sqdist3(qx, qy, qz, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
-            if (cnt < nsample && d2 < radius2) {
-                if (cnt == 0)
-                    for (int l = 0; l < nsample; ++l) o[l] = base + k;
-                o[cnt] = base + k;
-                ++cnt;
-            }
+    int *o = idx + ((size_t)b * m + p) * nsample;
+    int cnt = 0, first = -1;
+    for (int base = 0; base < n && cnt < nsample; base += 64) {
+        const int k = base + lane;
+        bool hit = false;
+        if (k < n) hit = mcp_sqdist3(qx, qy, qz, rb[(size_t)k * 3 + 0], rb[(size_t)k * 3 + 1], rb[(size_t)k * 3 + 2]) < radius2;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        if (mask) {
+            if (first < 0) first = base + (int)__builtin_ctzll(mask);
+            const int rank = cnt + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (hit && rank < nsample) o[rank] = k;
+            cnt += (int)__builtin_popcountll(mask);
         }
     }
+    if (first >= 0)
+        for (int l = min(cnt, nsample) + lane; l < nsample; l += 64) o[l] = first;
 }
 
 // K7  interpolate_gpu.cu:9-52.  Lane per unknown point; known points through an LDS tile.
@@ -258,8 +260,8 @@ MCP_EXPORT int mcp_ball_query(int b, int n, int m, float radius, int nsample, co
                               mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && m > 0 && nsample > 0 && new_xyz && xyz && idx);
     const float radius2 = radius * radius;  // ball_query_gpu.cu:20
-    hipLaunchKernelGGL(ball_query_kernel, dim3(mcp_divup(m, BLK), b), dim3(BLK), 0, (hipStream_t)stream, n, m, radius2, nsample,
-                       new_xyz, xyz, idx);
+    hipLaunchKernelGGL(ball_query_kernel, dim3(mcp_divup(m, BQ_WAVES), b), dim3(64 * BQ_WAVES), 0, (hipStream_t)stream, n, m, radius2,
+                       nsample, new_xyz, xyz, idx);
     return mcp_launch_status();
 }
 

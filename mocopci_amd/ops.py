@@ -42,10 +42,16 @@ class HipBackend:
     # clouds at least this large go through the Morton-sorted, box-pruned search (same results)
     PRUNE_MIN_REFS = 4096
     PRUNE_MIN_QUERIES = 1024
-    TILE = 128
 
     def __init__(self):
         self._clouds = []  # [(weakref(tensor), version, sorted_cloud)], most recent last
+        self._tile = None
+
+    @property
+    def TILE(self):
+        if self._tile is None:
+            self._tile = _lib.load().mcp_knn_tile_size()
+        return self._tile
 
     def _sorted_cloud(self, xyz):
         """Morton order of a cloud: (sorted xyz, perm int32, tile boxes).  Cached per tensor OBJECT (weakref +
