@@ -149,13 +149,16 @@ int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int
 
 /* Cost-volume cross() after its neighbour searches (pointconv_util.py:750-781, :894-922, :1126-1161):
  * xyz1 (B,N1,3), xyz2 (B,N2,3), points1 (B,N1,D), points2 (B,N2,D) channel-last (16-byte aligned),
- * idx (B,N1,32) int32 into set 2 (16 feature-cosine + 16 xyz neighbours), wpos (D,3), bpos (D) = the
- * Conv2d 3->D on xyz2[idx]-xyz1, wmlp (D,D), bmlp (D) = the single Conv2d D->D of the mlp list
- * (every layer MoCoPCI builds has exactly one) -> out (B,N1,D) = max over the 32 neighbours of
- * LeakyReLU(wmlp . LeakyReLU(points2[idx] + points1 + pos) + bmlp).  D in {64,128}, k must be 32. */
+ * idx (B,N1,32) int32 into set 2 (16 feature-cosine + 16 xyz neighbours) -> out (B,N1,D) = max over the 32
+ * neighbours of LeakyReLU(wmlp . LeakyReLU(points2[idx] + points1 + wpos.(xyz2[idx]-xyz1) + bpos) + bmlp).
+ * The layer's weights -- wpos (D,3), bpos (D) = the Conv2d 3->D; wmlp (D,D), bmlp (D) = the single Conv2d D->D of
+ * the mlp list (every layer MoCoPCI builds has exactly one) -- are packed ONCE per layer by mcp_cross_pack into
+ * the MFMA-operand image (mcp_cross_packed_floats(D) floats, 16-byte aligned, caller-owned).  D in {64,128}, k = 32. */
+int mcp_cross_packed_floats(int d);
+int mcp_cross_pack(int d, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, float *packed,
+                   mcp_stream_t stream);
 int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
-                     const float *points2, const int *idx, const float *wpos, const float *bpos, const float *wmlp,
-                     const float *bmlp, float *out, mcp_stream_t stream);
+                     const float *points2, const int *idx, const float *packed, float *out, mcp_stream_t stream);
 
 /* PointConv / PointConvD up to the final Linear (mocopci.py:1218-1266, :1289-1300, :1330-1335):
  * s_xyz (B,N,3), new_xyz (B,S,3) centres, s_points (B,N,D) channel-last, idx (B,S,32) int32 into the

@@ -38,7 +38,9 @@ SIGNATURES = {
     "mcp_interp3": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_fusion": [_i, _i, _i] + [_p] * 11,
-    "mcp_cross_volume": [_i] * 5 + [_p] * 11,
+    "mcp_cross_packed_floats": [_i],
+    "mcp_cross_pack": [_i, _p, _p, _p, _p, _p, _p],
+    "mcp_cross_volume": [_i] * 5 + [_p] * 8,
     "mcp_pointconv_agg": [_i] * 5 + [_p] * 12,
     "mcp_attention_small": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
     "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],

@@ -52,31 +52,47 @@ struct CrossLds {
     static constexpr int FLOATS = OFF_B + B_FLOATS;
 };
 
+// Packs (wpos, bpos, wmlp, bmlp) into the LDS image the kernel uses: done once per layer by the caller
+// (mcp_cross_pack), so a workgroup stages its weights with plain float4 copies.
 template <int D>
-__global__ __launch_bounds__(64 * WAVES) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
+__global__ __launch_bounds__(256) void cross_pack_kernel(const float *__restrict__ wpos, const float *__restrict__ bpos,
+                                                         const float *__restrict__ wmlp, const float *__restrict__ bmlp,
+                                                         float *__restrict__ packed) {
+    using L = CrossLds<D>;
+    constexpr int T = L::T, KQ = T * 4;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < L::FLOATS; e += gridDim.x * 256) {
+        float v;
+        if (e < L::OFF_POS) {  // [t][q][lane][4]: k-step s = 4q + j -> input tile s >> 4, register s & 15
+            const int j = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % KQ, t = (e >> 8) / KQ;
+            const int s = 4 * q + j, tin = s >> 4, r = s & 15;
+            v = wmlp[(32 * t + (lane & 31)) * D + 32 * tin + chan_of(r, lane >> 5)];
+        } else if (e < L::OFF_B) {  // [t][s][lane]: columns (dx,dy | dz,1)
+            const int f = e - L::OFF_POS, lane = f & 63, s = (f >> 6) & 1, t = f >> 7;
+            const int row = 32 * t + (lane & 31), c = 2 * s + (lane >> 5);
+            v = c < 3 ? wpos[row * 3 + c] : bpos[row];
+        } else {  // [t][h][r]
+            const int f = e - L::OFF_B, r = f & 15, h = (f >> 4) & 1, t = f >> 5;
+            v = bmlp[32 * t + chan_of(r, h)];
+        }
+        packed[e] = v;
+    }
+}
+
+// The kernel is latency-bound (one point in flight per wave through idx -> gathers -> MFMA -> reduce), so residency
+// matters more than unrolling: the output-tile loop is kept rolled and registers are capped for 3 (D=64) / 2 (D=128)
+// waves per SIMD.
+template <int D>
+__global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : 2)) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
                                                            const float *__restrict__ xyz2, const float *__restrict__ points1,
                                                            const float *__restrict__ points2, const int *__restrict__ idx,
-                                                           const float *__restrict__ wpos, const float *__restrict__ bpos,
-                                                           const float *__restrict__ wmlp, const float *__restrict__ bmlp,
-                                                           float *__restrict__ out) {
+                                                           const float *__restrict__ packed, float *__restrict__ out) {
     using L = CrossLds<D>;
     constexpr int T = L::T, KQ = T * 4;  // k-quads per output tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    for (int e = tid; e < L::W_FLOATS; e += 64 * WAVES) {
-        const int j = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % KQ, t = (e >> 8) / KQ;
-        const int s = 4 * q + j, tin = s >> 4, r = s & 15;
-        lds[L::OFF_W + e] = wmlp[(32 * t + (lane & 31)) * D + 32 * tin + chan_of(r, lane >> 5)];
-    }
-    for (int e = tid; e < L::POS_FLOATS; e += 64 * WAVES) {  // [t][s][lane]: columns (dx,dy | dz,1)
-        const int lane = e & 63, s = (e >> 6) & 1, t = e >> 7;
-        const int row = 32 * t + (lane & 31), c = 2 * s + (lane >> 5);
-        lds[L::OFF_POS + e] = c < 3 ? wpos[row * 3 + c] : bpos[row];
-    }
-    for (int e = tid; e < L::B_FLOATS; e += 64 * WAVES) {
-        const int r = e & 15, h = (e >> 4) & 1, t = e >> 5;
-        lds[L::OFF_B + e] = bmlp[32 * t + chan_of(r, h)];
-    }
+    static_assert(L::FLOATS % 4 == 0, "LDS image is copied as float4");
+    for (int e = tid; e < L::FLOATS / 4; e += 64 * WAVES)
+        reinterpret_cast<float4 *>(lds)[e] = reinterpret_cast<const float4 *>(packed)[e];
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_kernel(long long total, int 
             x0[t] = acc;
         }
         float4 *orow = reinterpret_cast<float4 *>(out + p * D);
-#pragma unroll
+#pragma unroll 1
         for (int t = 0; t < T; ++t) {
             f32x16 acc;
 #pragma unroll
@@ -141,8 +157,7 @@ __global__ __launch_bounds__(64 * WAVES) void cross_kernel(long long total, int 
 
 template <int D>
 int launch_cross(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
-                 const int *idx, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, float *out,
-                 hipStream_t s) {
+                 const int *idx, const float *packed, float *out, hipStream_t s) {
     const size_t lds = CrossLds<D>::FLOATS * sizeof(float);
     auto kern = cross_kernel<D>;
     static bool attr_done = false;
@@ -150,25 +165,40 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const unsigned grid = (unsigned)min((total + WAVES - 1) / WAVES, (long long)(lds > 40 * 1024 ? 512 : 1024));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp,
-                       bmlp, out);
+    // at least 8 points per wave so the weight staging is amortised
+    const long long want = (total + WAVES * 8 - 1) / (WAVES * 8);
+    const unsigned grid = (unsigned)max(1LL, min(want, (long long)(lds > 40 * 1024 ? 512 : 1024)));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out);
     return mcp_launch_status();
 }
 
 }  // namespace
 
+MCP_EXPORT int mcp_cross_packed_floats(int d) {
+    return d == 64 ? CrossLds<64>::FLOATS : d == 128 ? CrossLds<128>::FLOATS : 0;
+}
+
+MCP_EXPORT int mcp_cross_pack(int d, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, float *packed,
+                              mcp_stream_t stream) {
+    MCP_CHECK_ARGS(wpos && bpos && wmlp && bmlp && packed);
+    if (d != 64 && d != 128) return MCP_ERR_UNSUPPORTED;
+    if (((uintptr_t)packed) & 15) return MCP_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 64) hipLaunchKernelGGL(cross_pack_kernel<64>, dim3(16), dim3(256), 0, s, wpos, bpos, wmlp, bmlp, packed);
+    else hipLaunchKernelGGL(cross_pack_kernel<128>, dim3(64), dim3(256), 0, s, wpos, bpos, wmlp, bmlp, packed);
+    return mcp_launch_status();
+}
+
 MCP_EXPORT int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
-                                const float *points2, const int *idx, const float *wpos, const float *bpos, const float *wmlp,
-                                const float *bmlp, float *out, mcp_stream_t stream) {
-    MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && wpos && bpos && wmlp && bmlp && out);
+                                const float *points2, const int *idx, const float *packed, float *out, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && packed && out);
     if (k != KNB || (d != 64 && d != 128)) return MCP_ERR_UNSUPPORTED;
-    if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)out)) & 15) return MCP_ERR_BAD_ARG;
+    if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)out) | ((uintptr_t)packed)) & 15) return MCP_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)b * n1;
     mcp_prof_begin(MCP_KERNEL_CROSS, s);
-    const int rc = d == 64 ? launch_cross<64>(total, n1, n2, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, out, s)
-                           : launch_cross<128>(total, n1, n2, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, out, s);
+    const int rc = d == 64 ? launch_cross<64>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s)
+                           : launch_cross<128>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s);
     mcp_prof_end(MCP_KERNEL_CROSS, s);
     return rc;
 }

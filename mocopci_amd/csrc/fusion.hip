@@ -46,7 +46,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(64 * WAVES) void fusion_kernel(long long total, int n, const float *__restrict__ p1,
+__global__ __launch_bounds__(64 * WAVES, 2) void fusion_kernel(long long total, int n, const float *__restrict__ p1,
                                                             const float *__restrict__ p2, const int *__restrict__ idx,
                                                             const float *__restrict__ w1, const float *__restrict__ b1,
                                                             const float *__restrict__ w2, const float *__restrict__ b2,
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES) void fusion_kernel(long long total, int
             }
             // ---- layer 3: 64 -> 128, consumed into the channel max (max over ReLU = ReLU of max) ----
             float m = 0.f;
-#pragma unroll
+#pragma unroll 1
             for (int t = 0; t < 4; ++t) {
                 f32x16 acc;
 #pragma unroll

@@ -150,6 +150,8 @@ class MoCoPCI(nn.Module):
                 pc4 = self.fps_gather(pc3, 64)
                 done = torch.cuda.Event()
                 done.record(side)
+            for t in (pc1, pc2, pc3, pc4):  # allocated on the side stream, consumed on the main stream
+                t.record_stream(main)
         else:
             pc1 = self.fps_gather(xyz, 2048)
             pc2 = self.fps_gather(pc1, 512)
@@ -189,8 +191,11 @@ class MoCoPCI(nn.Module):
         D = points1.shape[-1]
         if len(mlp) == 1 and D in (64, 128) and points2.shape[-1] == D:
             conv = mlp[0] + ".composed_module.0"
-            return be.cross_volume(xyz1, xyz2, points1.contiguous(), points2.contiguous(), idx, self.W(pos), self.Bv(pos),
-                                   self.W(conv), self.Bv(conv))
+            P = self._params()
+            key = ("cross_pack", be.name, pos, conv)
+            if key not in P:  # the layer's weights in the kernel's operand layout, built once
+                P[key] = be.cross_pack(self.W(pos), self.Bv(pos), self.W(conv), self.Bv(conv))
+            return be.cross_volume(xyz1, xyz2, points1.contiguous(), points2.contiguous(), idx, P[key])
         direction = be.group_rows(xyz2, idx) - xyz1.unsqueeze(2)          # (B,N1,32,3)
         g2 = be.group_rows(points2, idx)                                  # (B,N1,32,D)
         x = leaky((g2 + points1.unsqueeze(2)) + self.lin(direction, pos))
@@ -424,6 +429,7 @@ class MoCoPCI(nn.Module):
                 down = self.fps_gather(warped, 2048)
                 done = torch.cuda.Event()
                 done.record(side)
+            down.record_stream(main)
         else:
             down = self.fps_gather(warped, 2048)
         wf = self.conv1d_block(wf, m + "rlevel0")

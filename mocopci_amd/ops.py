@@ -167,13 +167,26 @@ class HipBackend:
               _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(w3), _lib.fptr(b3), _lib.fptr(out))
         return out
 
-    def cross_volume(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp):
-        """cross() after its neighbour searches (pointconv_util.py:750-781): -> (B,N1,D); D in {64,128}."""
+    def cross_pack(self, wpos, bpos, wmlp, bmlp):
+        """Pack one cross layer's weights into the kernel's MFMA-operand image (do this once per layer)."""
+        D = wmlp.shape[0]
+        lib = _lib.load()
+        n = lib.mcp_cross_packed_floats(D)
+        if n == 0:
+            raise RuntimeError(f"cross_volume supports D in (64, 128), got {D}")
+        packed = torch.empty((n,), dtype=torch.float32, device=wmlp.device)
+        _call("mcp_cross_pack", wmlp, D, _lib.fptr(wpos.contiguous()), _lib.fptr(bpos.contiguous()), _lib.fptr(wmlp.contiguous()),
+              _lib.fptr(bmlp.contiguous()), _lib.fptr(packed))
+        return packed
+
+    def cross_volume(self, xyz1, xyz2, points1, points2, idx, packed):
+        """cross() after its neighbour searches (pointconv_util.py:750-781): -> (B,N1,D); D in {64,128};
+        packed = cross_pack(wpos, bpos, wmlp, bmlp)."""
         B, N1, D = points1.shape
         N2 = points2.shape[1]
         out = torch.empty((B, N1, D), dtype=torch.float32, device=points1.device)
         _call("mcp_cross_volume", points1, B, N1, N2, D, idx.shape[-1], _lib.fptr(xyz1), _lib.fptr(xyz2), _lib.fptr(points1),
-              _lib.fptr(points2), _lib.iptr(idx), _lib.fptr(wpos), _lib.fptr(bpos), _lib.fptr(wmlp), _lib.fptr(bmlp), _lib.fptr(out))
+              _lib.fptr(points2), _lib.iptr(idx), _lib.fptr(packed), _lib.fptr(out))
         return out
 
     def pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):

@@ -51,8 +51,12 @@ class OracleBackend:
         wgt = torch.softmax(x.max(dim=-1)[0], dim=-1)
         return torch.sum(wgt.unsqueeze(-1) * nb, dim=2)
 
-    def cross_volume(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp):
+    def cross_pack(self, wpos, bpos, wmlp, bmlp):
+        return (wpos, bpos, wmlp, bmlp)
+
+    def cross_volume(self, xyz1, xyz2, points1, points2, idx, packed):
         """Unfused restatement of pointconv_util.py:765-781 (one mlp layer)."""
+        wpos, bpos, wmlp, bmlp = packed
         F = torch.nn.functional
         direction = orc.group_rows(xyz2, idx.int()) - xyz1.unsqueeze(2)
         g2 = orc.group_rows(points2, idx.int())

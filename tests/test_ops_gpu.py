@@ -190,8 +190,11 @@ def test_cross_volume_matches_unfused_oracle(d, n1, n2):
     idx = torch.randint(0, n2, (B, n1, 32), generator=g, dtype=torch.int32)
     wpos, bpos = torch.randn(d, 3, generator=g) * 0.3, torch.randn(d, generator=g) * 0.1
     wmlp, bmlp = torch.randn(d, d, generator=g) / d ** 0.5, torch.randn(d, generator=g) * 0.1
-    want = OracleBackend().cross_volume(xyz1, xyz2, p1, p2, idx, wpos, bpos, wmlp, bmlp)
-    got = ops.backend().cross_volume(*[t.to(DEV) for t in (xyz1, xyz2, p1, p2, idx, wpos, bpos, wmlp, bmlp)]).cpu()
+    ob = OracleBackend()
+    want = ob.cross_volume(xyz1, xyz2, p1, p2, idx, ob.cross_pack(wpos, bpos, wmlp, bmlp))
+    be = ops.backend()
+    packed = be.cross_pack(*[t.to(DEV) for t in (wpos, bpos, wmlp, bmlp)])
+    got = be.cross_volume(*[t.to(DEV) for t in (xyz1, xyz2, p1, p2, idx)], packed).cpu()
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
 
 

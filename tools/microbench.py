@@ -16,6 +16,8 @@ idx64 = torch.randint(0, 8192, (24, 8192, 64), device=dev, dtype=torch.int32)
 w = lambda *s: torch.randn(*s, device=dev) * 0.1
 qa = torch.randn(80, 2048, 64, device=dev); kva = torch.randn(80, 2048, 128, device=dev)
 qb = torch.randn(80, 512, 128, device=dev); kvb = torch.randn(80, 512, 256, device=dev)
+pk64 = be.cross_pack(w(64, 3), w(64), w(64, 64), w(64)); pk128 = be.cross_pack(w(128, 3), w(128), w(128, 128), w(128))
+q512 = xyz16[:, :512].contiguous(); idx32b = torch.randint(0, 512, (16, 512, 32), device=dev, dtype=torch.int32)
 cases = {
     "fps 16x8192->2048": lambda: be.fps(xyz16, 2048),
     "fps 24x8192->2048": lambda: be.fps(xyz24, 2048),
@@ -27,7 +29,8 @@ cases = {
     "knn 24x8192qx2048 k3": lambda: be.knn(xyz24, xyz24[:, :2048].contiguous(), 3),
     "knn_cosine 16x2048 c64": lambda: be.knn_cosine(f64, f64b, 16),
     "knn_cosine 16x512 c128": lambda: be.knn_cosine(f128, f128b, 16),
-    "cross 16x2048 d64": lambda: be.cross_volume(q2048, q2048, f64, f64b, idx32, w(64, 3), w(64), w(64, 64), w(64)),
+    "cross 16x2048 d64": lambda: be.cross_volume(q2048, q2048, f64, f64b, idx32, pk64),
+    "cross 16x512 d128": lambda: be.cross_volume(q512, q512, f128, f128b, idx32b, pk128),
     "fusion 24x8192": lambda: be.fusion_mlp(xyz24, xyz24, idx64, w(64, 4), w(64), w(64, 64), w(64), w(128, 64), w(128)),
     "attention 80x8h x2048 hd8": lambda: be.attention(qa, kva, 8),
     "attention 80x8h x512 hd16": lambda: be.attention(qb, kvb, 8),
