@@ -22,3 +22,13 @@ def layer_inputs():
         "c576_a": _r(18, 1, 256, 576), "c576_b": _r(19, 1, 256, 576),
         "c192_a": _r(20, 1, 256, 192), "c192_b": _r(21, 1, 256, 192),
     }
+
+
+def big_cloud(n, seed=1, batch=1):
+    """Seeded LiDAR-like box cloud with 5 % duplicated points (full-size hash pins)."""
+    g = torch.Generator().manual_seed(1000 * seed + n)
+    x = (torch.rand(batch, n, 3, generator=g) * 2 - 1) * torch.tensor([40.0, 40.0, 3.0])
+    nd = n // 20
+    src = torch.randint(0, n - nd, (nd,), generator=g)
+    x[:, n - nd:] = x[:, src]
+    return x[:, torch.randperm(n, generator=g)].contiguous()

@@ -281,3 +281,22 @@ def test_attention_small_matches_fp32_reference(bf, nq, nk, heads, hd):
     want = OracleBackend().attention(q.double(), kv.double(), heads).float()   # float64 reference
     got = ops.backend().attention(q.to(DEV), kv.to(DEV), heads).cpu()
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_full_size_hash_pins():
+    """Bit-exactness at BASELINE sizes against SHA-256 pins of the oracle's outputs (oracle/make_hashes.py)."""
+    import hashlib, json, os
+    from tests.golden_inputs import big_cloud
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hashes.json")))
+    h = lambda t: hashlib.sha256(t.cpu().contiguous().numpy().tobytes()).hexdigest()
+    be = ops.backend()
+    for n, m in ((8192, 2048), (16384, 2048), (65536, 512)):
+        assert h(pu.furthest_point_sample(big_cloud(n).to(DEV), m)) == pins[f"fps_{n}_{m}"], (n, m)
+    for n, s in ((8192, 2048), (16384, 2048), (65536, 2048)):
+        _, i = pu.three_nn(big_cloud(n).to(DEV), big_cloud(s, seed=2).to(DEV))
+        assert h(i) == pins[f"three_nn_{n}_{s}"], (n, s)
+    x = big_cloud(8192).to(DEV)
+    assert h(be.knn(x, x, 32)) == pins["knn32_8192"]
+    x = big_cloud(16384).to(DEV)
+    assert h(be.knn(x, x, 16, mode=1)) == pins["knn16_direct_16384"]
+    assert h(pu.ball_query(1.0, 16, x, x[:, :2048].contiguous())) == pins["ball_query_16384_r1_16"]
