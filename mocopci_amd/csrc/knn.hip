@@ -19,67 +19,13 @@
 // lexicographic order (distance, index), ascending; distances in the canon of common.h.
 // Keys are uint64 (ord(d) << 32 | index), so every compare-exchange is one v_cmp_lt_u64.
 #include "common.h"
+#include "topk.h"
 
 namespace {
 
-typedef unsigned long long u64;
-constexpr u64 KEY_INF = ~0ull;
+typedef mcp_u64 u64;
+constexpr u64 KEY_INF = MCP_KEY_INF;
 constexpr int TILE = 256;  // reference points per LDS tile (per wave)
-
-__device__ __forceinline__ void ce_asc(u64 &a, u64 &b) {
-    const bool sw = b < a;
-    const u64 lo = sw ? b : a, hi = sw ? a : b;
-    a = lo;
-    b = hi;
-}
-__device__ __forceinline__ void ce_dir(u64 &a, u64 &b, bool up) {
-    const bool sw = up ? (b < a) : (a < b);
-    const u64 x = sw ? b : a, y = sw ? a : b;
-    a = x;
-    b = y;
-}
-
-template <int N>
-__device__ __forceinline__ void bitonic_sort(u64 (&v)[N]) {
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int l = i ^ j;
-                if (l > i) ce_dir(v[i], v[l], (i & k) == 0);
-            }
-        }
-    }
-}
-// v is bitonic -> ascending
-template <int N>
-__device__ __forceinline__ void bitonic_merge_asc(u64 (&v)[N]) {
-#pragma unroll
-    for (int j = N >> 1; j > 0; j >>= 1) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int l = i ^ j;
-            if (l > i) ce_asc(v[i], v[l]);
-        }
-    }
-}
-// a (K ascending) <- K smallest of a U q (QS ascending, QS <= K), ascending
-template <int K, int QS>
-__device__ __forceinline__ void merge_sorted(u64 (&a)[K], const u64 (&q)[QS]) {
-#pragma unroll
-    for (int i = K - QS; i < K; ++i) {
-        const u64 o = q[K - 1 - i];
-        a[i] = o < a[i] ? o : a[i];
-    }
-    bitonic_merge_asc<K>(a);
-}
-
-__device__ __forceinline__ float tau_of(u64 kth) {
-    const uint32_t hi = (uint32_t)(kth >> 32);
-    return hi == 0xFFFFFFFFu ? INFINITY : mcp_unord(hi);
-}
 
 template <int MODE>
 __device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float qn, const float4 r) {
@@ -159,10 +105,10 @@ __global__ __launch_bounds__(64 * SPLIT) void knn_small_kernel(int q, int n, int
                         u64 key = ((u64)mcp_ord(d[u]) << 32) | (uint32_t)(base + r0 + u);
                         key = d[u] < tau ? key : KEY_INF;
                         a[3] = key < a[3] ? key : a[3];
-                        ce_asc(a[2], a[3]);
-                        ce_asc(a[1], a[2]);
-                        ce_asc(a[0], a[1]);
-                        tau = tau_of(a[3]);
+                        mcp_ce_asc(a[2], a[3]);
+                        mcp_ce_asc(a[1], a[2]);
+                        mcp_ce_asc(a[0], a[1]);
+                        tau = mcp_tau_of(a[3]);
                     }
                 }
             }
@@ -184,22 +130,13 @@ __global__ __launch_bounds__(64 * SPLIT) void knn_small_kernel(int q, int n, int
             u64 o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = mrg[w][j][lane];
-            merge_sorted<4, 4>(a, o);
+            mcp_merge_sorted<4, 4>(a, o);
         }
     }
     if (!live) return;
     int *oi = idx + ((size_t)b * q + qi) * kout;
     float *od = dist ? dist + ((size_t)b * q + qi) * kout : nullptr;
-    u64 last = a[0];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j < kout) {
-            const u64 kk = a[j] == KEY_INF ? last : a[j];
-            last = kk;
-            oi[j] = kk == KEY_INF ? 0 : (int)(uint32_t)kk;
-            if (od) od[j] = kk == KEY_INF ? 0.f : mcp_unord((uint32_t)(kk >> 32));
-        }
-    }
+    mcp_store_list<4>(a, kout, oi, od);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,15 +183,8 @@ __global__ __launch_bounds__(64 * SPLIT) void knn_queue_kernel(int q, int n, int
     int cnt = 0;
 
     auto flush = [&]() {
-        u64 qk[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            const uint2 e = queue[s][lane];
-            qk[s] = s < cnt ? (((u64)mcp_ord(__uint_as_float(e.x)) << 32) | e.y) : KEY_INF;
-        }
-        bitonic_sort<QS>(qk);
-        merge_sorted<K, QS>(a, qk);
-        tau = tau_of(a[K - 1]);
+        mcp_flush_queue<K, QS>(a, queue, lane, cnt);
+        tau = mcp_tau_of(a[K - 1]);
         cnt = 0;
     };
 
@@ -315,22 +245,13 @@ __global__ __launch_bounds__(64 * SPLIT) void knn_queue_kernel(int q, int n, int
             u64 o[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) o[j] = om[j][lane];
-            merge_sorted<K, K>(a, o);
+            mcp_merge_sorted<K, K>(a, o);
         }
     }
     if (!live) return;
     int *oi = idx + ((size_t)b * q + qi) * kout;
     float *od = dist ? dist + ((size_t)b * q + qi) * kout : nullptr;
-    u64 last = a[0];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < kout) {
-            const u64 kk = a[j] == KEY_INF ? last : a[j];
-            last = kk;
-            oi[j] = kk == KEY_INF ? 0 : (int)(uint32_t)kk;
-            if (od) od[j] = kk == KEY_INF ? 0.f : mcp_unord((uint32_t)(kk >> 32));
-        }
-    }
+    mcp_store_list<K>(a, kout, oi, od);
 }
 
 // Chamfer helper: nearest squared distance from every x to the set y (direct form).

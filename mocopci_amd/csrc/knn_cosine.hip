@@ -15,57 +15,15 @@
 //     the end.
 // Result: the K smallest of d = 1 - dot under the lexicographic order (d, index), ascending.
 #include "common.h"
+#include "topk.h"
 
 namespace {
 
-typedef unsigned long long u64;
+typedef mcp_u64 u64;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr u64 KEY_INF = ~0ull;
+constexpr u64 KEY_INF = MCP_KEY_INF;
 constexpr int K = 16, QS = 16, CHK = 4, RT = 32, WAVES = 4;
 
-__device__ __forceinline__ void ce_asc(u64 &a, u64 &b) {
-    const bool sw = b < a;
-    const u64 lo = sw ? b : a, hi = sw ? a : b;
-    a = lo;
-    b = hi;
-}
-__device__ __forceinline__ void ce_dir(u64 &a, u64 &b, bool up) {
-    const bool sw = up ? (b < a) : (a < b);
-    const u64 x = sw ? b : a, y = sw ? a : b;
-    a = x;
-    b = y;
-}
-template <int N>
-__device__ __forceinline__ void bitonic_sort(u64 (&v)[N]) {
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int l = i ^ j;
-                if (l > i) ce_dir(v[i], v[l], (i & k) == 0);
-            }
-}
-template <int N>
-__device__ __forceinline__ void merge_equal(u64 (&a)[N], const u64 (&q)[N]) {  // both ascending -> a = N smallest
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const u64 o = q[N - 1 - i];
-        a[i] = o < a[i] ? o : a[i];
-    }
-#pragma unroll
-    for (int j = N >> 1; j > 0; j >>= 1)
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int l = i ^ j;
-            if (l > i) ce_asc(a[i], a[l]);
-        }
-}
-__device__ __forceinline__ float tau_of(u64 kth) {
-    const uint32_t hi = (uint32_t)(kth >> 32);
-    return hi == 0xFFFFFFFFu ? INFINITY : mcp_unord(hi);
-}
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // x / sqrt(sum(x^2) + 1e-8): sequential sum of rounded squares (oracle canon), one thread per row
@@ -106,15 +64,8 @@ __global__ __launch_bounds__(64 * WAVES) void knn_cosine_kernel(int q, int n, in
     float tau = INFINITY;
     int cnt = 0;
     auto flush = [&]() {
-        u64 qk[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            const uint2 e = queue[s][lane];
-            qk[s] = s < cnt ? (((u64)mcp_ord(__uint_as_float(e.x)) << 32) | e.y) : KEY_INF;
-        }
-        bitonic_sort<QS>(qk);
-        merge_equal<K>(a, qk);
-        tau = tau_of(a[K - 1]);
+        mcp_flush_queue<K, QS>(a, queue, lane, cnt);
+        tau = mcp_tau_of(a[K - 1]);
         cnt = 0;
     };
 
@@ -171,20 +122,11 @@ __global__ __launch_bounds__(64 * WAVES) void knn_cosine_kernel(int q, int n, in
         const uint32_t lo = __shfl_xor((uint32_t)a[j], 32), hi = __shfl_xor((uint32_t)(a[j] >> 32), 32);
         o[j] = ((u64)hi << 32) | lo;
     }
-    merge_equal<K>(a, o);
+    mcp_merge_sorted<K, K>(a, o);
     if (!live || h) return;
     int *oi = idx + ((size_t)b * q + qi) * kout;
     float *od = dist ? dist + ((size_t)b * q + qi) * kout : nullptr;
-    u64 last = a[0];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < kout) {
-            const u64 kk = a[j] == KEY_INF ? last : a[j];
-            last = kk;
-            oi[j] = kk == KEY_INF ? 0 : (int)(uint32_t)kk;
-            if (od) od[j] = kk == KEY_INF ? 0.f : mcp_unord((uint32_t)(kk >> 32));
-        }
-    }
+    mcp_store_list<K>(a, kout, oi, od);
 }
 
 template <int C>

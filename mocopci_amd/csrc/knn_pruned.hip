@@ -19,60 +19,18 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "topk.h"
 
 namespace {
 
-typedef unsigned long long u64;
-constexpr u64 KEY_INF = ~0ull;
+typedef mcp_u64 u64;
+constexpr u64 KEY_INF = MCP_KEY_INF;
 #ifndef MCP_PRUNED_PT
 #define MCP_PRUNED_PT 64
 #endif
 constexpr int PT = MCP_PRUNED_PT;  // references per tile
 constexpr int MAX_TPL = 16;  // tiles per lane -> up to 1024 tiles (N <= 65536 at 64 references per tile)
 
-__device__ __forceinline__ void ce_asc(u64 &a, u64 &b) {
-    const bool sw = b < a;
-    const u64 lo = sw ? b : a, hi = sw ? a : b;
-    a = lo;
-    b = hi;
-}
-__device__ __forceinline__ void ce_dir(u64 &a, u64 &b, bool up) {
-    const bool sw = up ? (b < a) : (a < b);
-    const u64 x = sw ? b : a, y = sw ? a : b;
-    a = x;
-    b = y;
-}
-template <int N>
-__device__ __forceinline__ void bitonic_sort(u64 (&v)[N]) {
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int l = i ^ j;
-                if (l > i) ce_dir(v[i], v[l], (i & k) == 0);
-            }
-}
-template <int K, int QS>
-__device__ __forceinline__ void merge_sorted(u64 (&a)[K], const u64 (&q)[QS]) {
-#pragma unroll
-    for (int i = K - QS; i < K; ++i) {
-        const u64 o = q[K - 1 - i];
-        a[i] = o < a[i] ? o : a[i];
-    }
-#pragma unroll
-    for (int j = K >> 1; j > 0; j >>= 1)
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const int l = i ^ j;
-            if (l > i) ce_asc(a[i], a[l]);
-        }
-}
-__device__ __forceinline__ float tau_of(u64 kth) {
-    const uint32_t hi = (uint32_t)(kth >> 32);
-    return hi == 0xFFFFFFFFu ? INFINITY : mcp_unord(hi);
-}
 __device__ __forceinline__ float wave_minf(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -326,15 +284,8 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
     float tau = tau_own;                          // shared push threshold of the query's SUB lanes
     int cnt = 0;
     auto flush = [&]() {
-        u64 qk[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            const uint2 e = queue[s][lane];
-            qk[s] = s < cnt ? (((u64)mcp_ord(__uint_as_float(e.x)) << 32) | e.y) : KEY_INF;
-        }
-        bitonic_sort<QS>(qk);
-        merge_sorted<K, QS>(a, qk);
-        if (live) tau_own = tau_of(a[K - 1]);
+        mcp_flush_queue<K, QS>(a, queue, lane, cnt);
+        if (live) tau_own = mcp_tau_of(a[K - 1]);
         tau = sub_min<SUB>(tau_own);
         cnt = 0;
     };
@@ -418,29 +369,20 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
 #pragma unroll
         for (int j = 0; j < K; ++j)
             o[j] = ((u64)mcp_dpp<0xB1>((uint32_t)(a[j] >> 32)) << 32) | mcp_dpp<0xB1>((uint32_t)a[j]);
-        merge_sorted<K, K>(a, o);
+        mcp_merge_sorted<K, K>(a, o);
     }
     if (SUB >= 4) {
         u64 o[K];
 #pragma unroll
         for (int j = 0; j < K; ++j)
             o[j] = ((u64)mcp_dpp<0x4E>((uint32_t)(a[j] >> 32)) << 32) | mcp_dpp<0x4E>((uint32_t)a[j]);
-        merge_sorted<K, K>(a, o);
+        mcp_merge_sorted<K, K>(a, o);
     }
     if (!live || sub != 0) return;
     const int row = qperm ? qperm[(size_t)b * q + qi] : qi;
     int *oi = idx + ((size_t)b * q + row) * kout;
     float *od = dist ? dist + ((size_t)b * q + row) * kout : nullptr;
-    u64 last = a[0];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < kout) {
-            const u64 kk = a[j] == KEY_INF ? last : a[j];
-            last = kk;
-            oi[j] = kk == KEY_INF ? 0 : (int)(uint32_t)kk;
-            if (od) od[j] = kk == KEY_INF ? 0.f : mcp_unord((uint32_t)(kk >> 32));
-        }
-    }
+    mcp_store_list<K>(a, kout, oi, od);
 }
 
 template <int K, int MODE, int SUB>
