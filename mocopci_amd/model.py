@@ -213,6 +213,13 @@ class MoCoPCI(nn.Module):
         idx3, w3 = cache[key]
         return be.interp3_apply(feat, idx3, w3)
 
+    def interp_flows(self, dense, sparse, flows, cache, key):
+        """The three per-frame flow upsamples (mocopci.py:870-878, :936-944) as ONE interpolation: flows (B,3,S,3) are
+        laid side by side as 9 channels (same 3-NN and weights for all of them)."""
+        B, R, S, _ = flows.shape
+        up = self.interp(dense, sparse, flows.permute(0, 2, 1, 3).reshape(B, S, R * 3), cache, key)      # (B,N,9)
+        return [up[..., 3 * i:3 * i + 3].contiguous() for i in range(R)]
+
     def warp(self, xyz1, xyz2, flow1):
         """PointWarping.forward (mocopci.py:1458-1482)."""
         return xyz2 - ops.backend().interp3(xyz2, xyz1 + flow1, flow1)
@@ -309,12 +316,21 @@ class MoCoPCI(nn.Module):
         half = f1_0.shape[0] // 2
         idx_c12 = ops.backend().knn_cosine(f1_0, f2_0, 16)
         idx_c21 = torch.cat([idx_c12[half:], idx_c12[:half]], dim=0)
-        for up in up_frames:
-            pc2w = self.warp(pc1, pc2, up)
-            n1 = self.cross(pc1, pc2w, t11_1, t22_2, f1_0, f2_0, b + ".pos", bid_mlp, True, idx_c12)
-            n2 = self.cross(pc2w, pc1, t11_2, t22_1, f2_0, f1_0, b + ".pos", bid_mlp, True, idx_c21)
-            fes.append(self.cross(pc1, pc2w, self.lin(n1, fe + ".conv1"), self.lin(n2, fe + ".conv2"), f1_0, f2_0,
-                                  fe + ".pos", fe_mlp, False, idx_c12))
+        # The loop over the 3 upsampled flows (mocopci.py:191-197) has no carried dependency -- the bid/fe layers always
+        # see the original c_feat1/c_feat2 -- so the three iterations run as one batch of 3 x (2B); feat1_new/feat2_new
+        # after the loop are those of the last iteration.
+        R = len(up_frames)
+        rep = lambda t: t.unsqueeze(0).expand(R, *t.shape).reshape(R * t.shape[0], *t.shape[1:])
+        pc1r, pc2r = rep(pc1), rep(pc2)
+        ic12, ic21 = rep(idx_c12), rep(idx_c21)
+        pc2w = self.warp(pc1r, pc2r, torch.cat(list(up_frames), dim=0))
+        n1a = self.cross(pc1r, pc2w, rep(t11_1), rep(t22_2), None, None, b + ".pos", bid_mlp, True, ic12)
+        n2a = self.cross(pc2w, pc1r, rep(t11_2), rep(t22_1), None, None, b + ".pos", bid_mlp, True, ic21)
+        fea = self.cross(pc1r, pc2w, self.lin(n1a, fe + ".conv1"), self.lin(n2a, fe + ".conv2"), None, None, fe + ".pos", fe_mlp,
+                         False, ic12)
+        B2 = pc1.shape[0]
+        fes = list(fea.reshape(R, B2, *fea.shape[1:]).unbind(0))
+        n1, n2 = n1a[(R - 1) * B2:], n2a[(R - 1) * B2:]
         x = torch.stack([n1, *fes, n2], dim=1) + time_enc                          # (B,5,N,C)
         xf, frames = self.multi_frame_att(prefix + ".cross_block", x)              # (B,3,N,latent),(B,3,N,3)
         feat_frames = self.conv1d_block(xf, prefix + ".downsample")                # (B,3,N,C)
@@ -388,7 +404,7 @@ class MoCoPCI(nn.Module):
         f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
 
         def level(prefix, lvl, f_up, frames_prev, key):
-            ups = [self.interp(pcs[lvl], pcs[lvl + 1], frames_prev[:, i].contiguous(), cache, key) for i in range(3)]
+            ups = self.interp_flows(pcs[lvl], pcs[lvl + 1], frames_prev, cache, key)
             C = feats[lvl].shape[-1]
             te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
                            dim=0).unsqueeze(2)                                      # (2B,5,1,C)
@@ -404,7 +420,7 @@ class MoCoPCI(nn.Module):
         # forward call gets (feat1_l2_1_f, feat2_l2_1_f); backward call gets (feat2_l2_1_b, feat1_l2_1_b)
         f_up_1 = torch.cat([f1_up[:B], f2_up[B:]], dim=0)
         f_up_1_o = torch.cat([f1_up[B:], f2_up[:B]], dim=0)
-        ups = [self.interp(pcs[1], pcs[2], frame2s[:, i].contiguous(), cache, "21") for i in range(3)]
+        ups = self.interp_flows(pcs[1], pcs[2], frame2s, cache, "21")
         C = feats[1].shape[-1]
         te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
                        dim=0).unsqueeze(2)
