@@ -51,6 +51,22 @@ __device__ __forceinline__ uint32_t fps_unsec(uint32_t sec, int L) {
 // maximum in ascending p.  J == 1 (T = bs/2): a thread holds two reference threads (even p -> tid,
 // odd p -> tid + T); bitrev_L(tid + T) = bitrev_L(tid) + 1, so among equal values the even-p points win,
 // each group in ascending p.  GENERIC (n < 64): every compare uses the full (ord, ~sec) pair.
+#ifdef MCP_FPS_DIAG
+// diagnostic build only: per-phase shader-cycle totals of wave 0 (never compiled into the product library)
+__device__ unsigned long long g_fps_diag[8];
+#define FPS_STAMP(slot)                                                                          \
+    do {                                                                                         \
+        unsigned long long t_;                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_fps_diag[slot] += t_ - t_prev;                 \
+        t_prev = t_;                                                                             \
+    } while (0)
+#else
+#define FPS_STAMP(slot)
+#endif
+
 template <int T, int P, int J, bool GENERIC, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, const float *__restrict__ xyz,
                                                          float *__restrict__ temp, int *__restrict__ idxs) {
@@ -87,6 +103,10 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
 
     int old = 0;
     int s_cur = 0, s_nxt = 1;
+#ifdef MCP_FPS_DIAG
+    unsigned long long t_prev = 0;
+    FPS_STAMP(7);
+#endif
     for (int j = 1; j < m; ++j) {
         float x1, y1, z1;
         if (LDS_XYZ) {
@@ -94,6 +114,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
         } else {
             x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
         }
+        FPS_STAMP(0);  // centre read
         uint32_t hi, lo;
         if (!GENERIC) {
             // track only the maximum VALUE in the scan (packed fp32 math); which point holds it is found afterwards
@@ -116,8 +137,11 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
                 best = fmaxf(-1.0f, pt[0]);
             }
             hi = mcp_ord(best);
+            FPS_STAMP(1);  // scan
             const uint32_t whi = mcp_wave_max_u32(hi);
-            // tie order inside the thread: reverse-priority assignment chain, highest priority assigned last
+            // tie order inside the thread: reverse-priority assignment chain, highest priority assigned last.
+            // (An independent-select + max-tree form was measured 4 % SLOWER: this phase is bound by instruction
+            // count -- about 12 cycles per instruction with the DPP / SGPR-mask hazards -- not by the chain's depth.)
             uint32_t bsec = 0;
             if constexpr (J == 1) {
 #pragma unroll
@@ -147,11 +171,13 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
             hi = whi;
         }
         uint32_t wlo = mcp_wave_max_u32(lo);
+        FPS_STAMP(2);  // wave reductions + index select
         if (W > 1) {
             // cross-wave: one LDS atomic max per wave on a rotating slot, one barrier, one broadcast read
             if (lane == 0) atomicMax(&slots[s_cur], ((unsigned long long)hi << 32) | wlo);
             if (tid == 0) slots[s_nxt] = 0ull;
             __syncthreads();
+            FPS_STAMP(3);  // LDS atomic + barrier
             wlo = (uint32_t)slots[s_cur];
             const int s_new = 3 - s_cur - s_nxt;
             s_cur = s_nxt;
@@ -159,6 +185,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
         }
         old = (int)fps_unsec(~wlo, L);
         if (tid == 0) idxs[j] = old;
+        FPS_STAMP(4);  // slot read + decode + store
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -234,6 +261,15 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
 }
 
 }  // namespace
+
+#ifdef MCP_FPS_DIAG
+extern "C" __attribute__((visibility("default"))) int mcp_fps_diag_read(unsigned long long *out8) {
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fps_diag), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_diag), z, sizeof(z));
+    return (int)e;
+}
+#endif
 
 MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && temp && idx);
