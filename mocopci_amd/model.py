@@ -105,10 +105,14 @@ class MoCoPCI(nn.Module):
         return leaky(self.lin(x, name + ".composed_module.0"))
 
     def bn_eval(self, x, name, eps):
-        """BatchNorm in eval mode on a channel-last tensor."""
+        """BatchNorm in eval mode on a channel-last tensor: one fused multiply-add with cached (scale, shift)."""
         P = self._params()
-        scale = P[name + ".weight"] * torch.rsqrt(P[name + ".running_var"] + eps)
-        return (x - P[name + ".running_mean"]) * scale + P[name + ".bias"]
+        key = ("bn", name, eps)
+        if key not in P:
+            scale = P[name + ".weight"] * torch.rsqrt(P[name + ".running_var"] + eps)
+            P[key] = (scale.contiguous(), (P[name + ".bias"] - P[name + ".running_mean"] * scale).contiguous())
+        scale, shift = P[key]
+        return torch.addcmul(shift, x, scale)
 
     # ---- point-set layers ---------------------------------------------------------------
     def pointconv(self, prefix, s_xyz, new_xyz, s_points, nsample=32):
@@ -264,11 +268,16 @@ class MoCoPCI(nn.Module):
         return xa[:, 1:], frames[:, 1:]                                           # (B,3,N,C), (B,3,N,3)
 
     def mlp_t(self, prefix, x):
-        """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2."""
+        """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2.  The depthwise k=1 conv is a
+        per-channel scale + bias, folded into fc1 once: (W x + b) * s + t = (s W) x + (s b + t)."""
         P = self._params()
-        h = self.lin(x, prefix + ".fc1")
-        h = h * P[prefix + ".dwconv.dwconv.weight"].reshape(-1) + P[prefix + ".dwconv.dwconv.bias"]
-        return self.lin(F.prelu(h, P[prefix + ".act.weight"]), prefix + ".fc2")
+        key = ("mlp_t_fc1", prefix)
+        if key not in P:
+            sc = P[prefix + ".dwconv.dwconv.weight"].reshape(-1)
+            P[key] = ((self.W(prefix + ".fc1") * sc[:, None]).contiguous(),
+                      (self.Bv(prefix + ".fc1") * sc + P[prefix + ".dwconv.dwconv.bias"]).contiguous())
+        w1, b1 = P[key]
+        return self.lin(F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"]), prefix + ".fc2")
 
     def multi_frame_att(self, prefix, x, heads=8):
         """Multi_Frame_Att.forward (mocopci.py:551-575) batched.  x (B,5,N,C)."""
