@@ -350,16 +350,15 @@ class MoCoPCI(nn.Module):
         neighbours (direct squared distance; the reference's full argsort is replaced by the KNN kernel)."""
         be = ops.backend()
         idx = be.knn(xyz, xyz, k, mode=ops.MCP_DIST_DIRECT)
-        knn_xyz = be.group_rows(xyz, idx)
         x = self.lin(feats, prefix + ".fc1")
-        q = self.lin(x, prefix + ".w_qs")
-        kk = be.group_rows(self.lin(x, prefix + ".w_ks").contiguous(), idx)
-        v = be.group_rows(self.lin(x, prefix + ".w_vs").contiguous(), idx)
-        pos = self.lin(F.relu(self.lin(xyz.unsqueeze(2) - knn_xyz, prefix + ".fc_delta.0")), prefix + ".fc_delta.2")
-        g = (q.unsqueeze(2) - kk) + pos
-        attn = self.lin(F.relu(self.lin(g, prefix + ".fc_gamma.0")), prefix + ".fc_gamma.2")
-        attn = F.softmax(attn / math.sqrt(kk.shape[-1]), dim=-2)
-        res = torch.sum(attn * (v + pos), dim=2)
+        P = self._params()
+        key = ("ptblock_pack", be.name, prefix)
+        if key not in P:
+            P[key] = be.ptblock_pack(self.W(prefix + ".fc_delta.0"), self.Bv(prefix + ".fc_delta.0"), self.W(prefix + ".fc_delta.2"),
+                                     self.Bv(prefix + ".fc_delta.2"), self.W(prefix + ".fc_gamma.0"), self.Bv(prefix + ".fc_gamma.0"),
+                                     self.W(prefix + ".fc_gamma.2"), self.Bv(prefix + ".fc_gamma.2"))
+        res = be.ptblock_attention(xyz, self.lin(x, prefix + ".w_qs"), self.lin(x, prefix + ".w_ks"), self.lin(x, prefix + ".w_vs"), idx,
+                                   P[key])
         return self.lin(res, prefix + ".fc2") + feats
 
     def folded_conv_bn(self, conv, bn, eps):

@@ -189,6 +189,21 @@ class HipBackend:
               _lib.fptr(points2), _lib.iptr(idx), _lib.fptr(packed), _lib.fptr(out))
         return out
 
+    def ptblock_pack(self, wd1, bd1, wd2, bd2, wg1, bg1, wg2, bg2):
+        """Pack fc_delta / fc_gamma of a TransformerBlock (pointT_layer2.py:42-51) into the kernel's operand image."""
+        packed = torch.empty((_lib.load().mcp_ptblock_packed_floats(),), dtype=torch.float32, device=wd2.device)
+        args = [t.contiguous() for t in (wd1, bd1, wd2, bd2, wg1, bg1, wg2, bg2)]
+        _call("mcp_ptblock_pack", wd2, *[_lib.fptr(t) for t in args], _lib.fptr(packed))
+        return packed
+
+    def ptblock_attention(self, xyz, q, k, v, idx, packed):
+        """Vector attention of TransformerBlock.forward (pointT_layer2.py:68-75) after knn + projections: -> (B,N,64)."""
+        B, N, C = q.shape
+        out = torch.empty((B, N, C), dtype=torch.float32, device=q.device)
+        _call("mcp_ptblock_attention", q, B, N, C, idx.shape[-1], _lib.fptr(xyz), _lib.fptr(q), _lib.fptr(k), _lib.fptr(v), _lib.iptr(idx),
+              _lib.fptr(packed), _lib.fptr(out))
+        return out
+
     def pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
         """PointConv grouping + WeightNet + aggregation (mocopci.py:1330-1335): -> (B,S,(3+D)*8)."""
         B, N, D = s_points.shape

@@ -64,6 +64,20 @@ class OracleBackend:
         x = F.leaky_relu(F.linear(x, wmlp, bmlp), 0.1)
         return x.max(dim=2)[0]
 
+    def ptblock_pack(self, *weights):
+        return weights
+
+    def ptblock_attention(self, xyz, q, k, v, idx, packed):
+        """Unfused restatement of pointT_layer2.py:64-75 (after knn and the q/k/v projections)."""
+        F = torch.nn.functional
+        wd1, bd1, wd2, bd2, wg1, bg1, wg2, bg2 = packed
+        knn_xyz = orc.group_rows(xyz, idx.int())
+        kk, vv = orc.group_rows(k, idx.int()), orc.group_rows(v, idx.int())
+        pos = F.linear(torch.relu(F.linear(xyz.unsqueeze(2) - knn_xyz, wd1, bd1)), wd2, bd2)
+        attn = F.linear(torch.relu(F.linear((q.unsqueeze(2) - kk) + pos, wg1, bg1)), wg2, bg2)
+        attn = torch.softmax(attn / (kk.shape[-1] ** 0.5), dim=-2)
+        return torch.sum(attn * (vv + pos), dim=2)
+
     def pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
         """Unfused restatement of mocopci.py:1218-1266 + :1289-1300 + :1330-1335."""
         F = torch.nn.functional

@@ -300,3 +300,21 @@ def test_full_size_hash_pins():
     x = big_cloud(16384).to(DEV)
     assert h(be.knn(x, x, 16, mode=1)) == pins["knn16_direct_16384"]
     assert h(pu.ball_query(1.0, 16, x, x[:, :2048].contiguous())) == pins["ball_query_16384_r1_16"]
+
+
+@pytest.mark.parametrize("n", [2048, 333])
+def test_ptblock_attention_matches_unfused_oracle(n):
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(n)
+    B = 2
+    xyz = cloud(141, B, n)
+    q, k, v = (torch.randn(B, n, 64, generator=g) for _ in range(3))
+    idx = orc.knn(xyz, xyz, 16, mode=1)
+    ws = [torch.randn(64, 3, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1]
+    for _ in range(3):
+        ws += [torch.randn(64, 64, generator=g) / 8, torch.randn(64, generator=g) * 0.1]
+    ob = OracleBackend()
+    want = ob.ptblock_attention(xyz, q, k, v, idx, ob.ptblock_pack(*ws))
+    be = ops.backend()
+    got = be.ptblock_attention(*[t.to(DEV) for t in (xyz, q, k, v, idx)], be.ptblock_pack(*[w.to(DEV) for w in ws])).cpu()
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
