@@ -16,6 +16,7 @@
 //   (ord(d2), ~sec(k)),  sec(k) = bitrev_L(k mod bs) << (32-L) | (k >> L)
 // by max.  Distances use the canon of common.h (= oracle/pointset_oracle.c).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -194,6 +195,194 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Spatially pruned variant (n >= MCP_FPS_SPATIAL_MIN).  The resident kernel above is bound by VALU issue:
+// every wave re-evaluates all of its points on every iteration although a new centre can only lower the
+// running distance of points closer to it than their current value.  Here the workgroup first sorts its
+// cloud along a Morton curve (18-bit isotropic cells, in LDS), so a lane owns P consecutive points of the
+// curve (a small cell, bounding box in 6 VGPRs) and a wave owns one compact region.  Per iteration a lane
+// computes the squared distance from the centre to its box, in the same arithmetic as the point distances:
+// fp32 subtraction, multiplication and fma are monotone, so that value is an exact lower bound of every
+// point distance the lane would compute, and when it is >= the lane's largest running distance nothing in
+// the lane can change.  A wave in which no lane can change skips the update and re-submits its cached
+// (value, key) maximum.  On LiDAR-like clouds about 2 of 16 waves update per iteration.  Results are
+// bit-identical to the resident kernel: the (ord(d), ~sec(k)) order is total, so neither the arrangement of
+// points nor skipping unchanged waves can alter the winner.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fps_spread6(uint32_t v) {  // 6 bits -> every third bit
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) r |= ((v >> b) & 1u) << (3 * b);
+    return r;
+}
+
+template <int T, int P, bool LDS_XYZ>
+__global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, const float *__restrict__ xyz,
+                                                        float *__restrict__ temp, int *__restrict__ idxs) {
+    constexpr int W = T / 64, NS = T * P;  // NS: sort size, a power of two with n <= NS <= 16384
+    extern __shared__ float4 smem_f4[];
+    // header (512 B): [0,24) rotating max slots, [64,448) bbox reduction scratch, [448,472) cloud bbox
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_f4);
+    float(*red)[16] = reinterpret_cast<float(*)[16]>(reinterpret_cast<float *>(smem_f4) + 16);
+    float *bbox = reinterpret_cast<float *>(smem_f4) + 112;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem_f4) + 512);  // [NS] during the sort
+    float *sxyz = reinterpret_cast<float *>(reinterpret_cast<char *>(smem_f4) + 512);        // [n*3] afterwards
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    xyz += (size_t)blockIdx.x * n * 3;
+    temp += (size_t)blockIdx.x * n;
+    idxs += (size_t)blockIdx.x * m;
+
+    // 1. bounding box of the cloud
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = tid; i < n; i += T) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = xyz[(size_t)i * 3 + a];
+                lo[a] = fminf(lo[a], v);
+                hi[a] = fmaxf(hi[a], v);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // max of ord() is max of the float; min via negation
+            const float l = -mcp_unord(mcp_wave_max_u32(mcp_ord(-lo[a]))), h = mcp_unord(mcp_wave_max_u32(mcp_ord(hi[a])));
+            if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+        }
+        if (tid < 3) slots[tid] = 0ull;
+        __syncthreads();
+        if (tid < 6) {
+            float v = red[tid][0];
+            for (int w = 1; w < W; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+            bbox[tid] = v;
+        }
+        __syncthreads();
+    }
+    // 2. keys: 18-bit Morton code of isotropic cells (LiDAR clouds are flat) above the 14-bit point index
+    {
+        const float ext = fmaxf(fmaxf(bbox[3] - bbox[0], bbox[4] - bbox[1]), bbox[5] - bbox[2]);
+        for (int i = tid; i < NS; i += T) {
+            uint32_t k = 0xFFFFFFFFu;
+            if (i < n) {
+                uint32_t c[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float t = ext > 0.f ? (xyz[(size_t)i * 3 + a] - bbox[a]) / ext : 0.f;
+                    t = fminf(fmaxf(t * 64.f, 0.f), 63.f);
+                    c[a] = (uint32_t)t;
+                }
+                k = ((fps_spread6(c[0]) | (fps_spread6(c[1]) << 1) | (fps_spread6(c[2]) << 2)) << 14) | (uint32_t)i;
+            }
+            keys[i] = k;
+        }
+        __syncthreads();
+    }
+    // 3. bitonic sort in LDS
+    for (int k = 2; k <= NS; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int u = 0; u < P / 2; ++u) {
+                const int p = tid + T * u;
+                const int i = 2 * p - (p & (j - 1));
+                const int l = i + j;
+                const uint32_t x = keys[i], y = keys[l];
+                const bool up = (i & k) == 0;
+                if ((y < x) == up) { keys[i] = y; keys[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    // 4. a lane takes P consecutive points of the curve; box of the valid ones
+    float px[P], py[P], pz[P], pt[P];
+    uint32_t nsec[P];
+    float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
+    float best = -1.0f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int s = tid * P + p;
+        const bool ok = s < n;  // the n real keys sort in front of the padding
+        const int src = ok ? (int)(keys[s] & 0x3FFFu) : 0;
+        px[p] = xyz[src * 3 + 0];
+        py[p] = xyz[src * 3 + 1];
+        pz[p] = xyz[src * 3 + 2];
+        pt[p] = ok ? temp[src] : -INFINITY;  // never selected, never stored
+        nsec[p] = ~fps_sec((uint32_t)src, L);
+        if (ok) {
+            lox = fminf(lox, px[p]); loy = fminf(loy, py[p]); loz = fminf(loz, pz[p]);
+            hix = fmaxf(hix, px[p]); hiy = fmaxf(hiy, py[p]); hiz = fmaxf(hiz, pz[p]);
+            best = fmaxf(best, pt[p]);
+        }
+    }
+    __syncthreads();  // keys are dead: the region is reused for the coordinates
+    if (LDS_XYZ) {
+        for (int i = tid; i < n * 3; i += T) sxyz[i] = xyz[i];
+    }
+    if (tid == 0) idxs[0] = 0;
+    __syncthreads();
+
+    int old = 0;
+    int s_cur = 0, s_nxt = 1;
+    uint32_t c_hi = 0, c_lo = 0;  // the wave's cached maximum (wave-uniform)
+#ifdef MCP_FPS_DIAG
+    unsigned long long t_prev = 0;
+    FPS_STAMP(7);
+#endif
+    for (int j = 1; j < m; ++j) {
+        float x1, y1, z1;
+        if (LDS_XYZ) {
+            x1 = sxyz[old * 3 + 0]; y1 = sxyz[old * 3 + 1]; z1 = sxyz[old * 3 + 2];
+        } else {
+            x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
+        }
+        FPS_STAMP(0);  // centre read
+        // exact lower bound of the lane's point distances (see the header comment); an all-padding lane has best = -1
+        const float ex = fmaxf(fmaxf(lox - x1, x1 - hix), 0.f), ey = fmaxf(fmaxf(loy - y1, y1 - hiy), 0.f),
+                    ez = fmaxf(fmaxf(loz - z1, z1 - hiz), 0.f);
+        const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+        const bool need = lb < best;
+        FPS_STAMP(1);  // box test
+        if (j == 1 || __builtin_amdgcn_ballot_w64(need)) {
+            const f2 c0 = {x1, x1}, c1 = {y1, y1}, c2 = {z1, z1};
+            f2 m2 = {-1.0f, -1.0f};
+#pragma unroll
+            for (int p = 0; p < P; p += 2) {
+                const f2 dx = f2{px[p], px[p + 1]} - c0, dy = f2{py[p], py[p + 1]} - c1, dz = f2{pz[p], pz[p + 1]} - c2;
+                const f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                pt[p] = fminf(d.x, pt[p]);
+                pt[p + 1] = fminf(d.y, pt[p + 1]);
+                m2.x = fmaxf(m2.x, pt[p]);
+                m2.y = fmaxf(m2.y, pt[p + 1]);
+            }
+            best = fmaxf(m2.x, m2.y);
+            const uint32_t hi = mcp_ord(best);
+            const uint32_t whi = mcp_wave_max_u32(hi);
+            uint32_t bsec = 0;  // points sit in curve order, so ties inside the lane compare the keys themselves
+#pragma unroll
+            for (int p = 0; p < P; ++p) bsec = max(bsec, pt[p] == best ? nsec[p] : 0u);
+            c_lo = mcp_wave_max_u32(hi == whi ? bsec : 0u);
+            c_hi = whi;
+        }
+        FPS_STAMP(2);  // update + wave reductions
+        if (lane == 0) atomicMax(&slots[s_cur], ((unsigned long long)c_hi << 32) | c_lo);
+        if (tid == 0) slots[s_nxt] = 0ull;
+        __syncthreads();
+        FPS_STAMP(3);  // LDS atomic + barrier
+        const uint32_t wlo = (uint32_t)slots[s_cur];
+        const int s_new = 3 - s_cur - s_nxt;
+        s_cur = s_nxt;
+        s_nxt = s_new;
+        old = (int)fps_unsec(~wlo, L);
+        if (tid == 0) idxs[j] = old;
+        FPS_STAMP(4);  // slot read + decode + store
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (tid * P + p < n) temp[fps_unsec(~nsec[p], L)] = pt[p];
+    }
+}
+
 // Large-N fallback (N > 16 points per lane at 1024 threads): temp stays in global memory,
 // xyz is re-read from L2 each iteration, same (ord, ~sec) reduction.  Correct for any N.
 __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int L, const float *__restrict__ xyz,
@@ -260,6 +449,63 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
     return mcp_launch_status();
 }
 
+template <int T, int P>
+int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
+    const size_t head = 512, key_bytes = (size_t)T * P * 4, xyz_bytes = (size_t)n * 3 * sizeof(float);
+    const bool lds_xyz = head + xyz_bytes <= 160 * 1024;
+    const size_t lds = head + (lds_xyz && xyz_bytes > key_bytes ? xyz_bytes : key_bytes);
+    static bool attr_done = false;  // benign race: the attribute is idempotent
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_done = true;
+    }
+    if (lds_xyz) hipLaunchKernelGGL((fps_spatial_kernel<T, P, true>), dim3(b), dim3(T), lds, s, n, m, L, xyz, temp, idx);
+    else hipLaunchKernelGGL((fps_spatial_kernel<T, P, false>), dim3(b), dim3(T), lds, s, n, m, L, xyz, temp, idx);
+    return mcp_launch_status();
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// workgroup size for the spatial kernel by sort size (tuning override: MCP_FPS_T)
+int launch_spatial_any(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
+    static const int force_t = env_int("MCP_FPS_T", 0);
+    int ns = 2048;
+    while (ns < n) ns <<= 1;
+    const int t = force_t ? force_t : 1024;
+    switch (ns / t) {
+#define MCP_FPS_CASE(T, P) \
+    case P:                \
+        if (t == T) return launch_spatial<T, P>(b, n, m, L, xyz, temp, idx, s); \
+        break;
+        case 2: if (t == 1024) return launch_spatial<1024, 2>(b, n, m, L, xyz, temp, idx, s); break;
+        case 4:
+            if (t == 1024) return launch_spatial<1024, 4>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 512) return launch_spatial<512, 4>(b, n, m, L, xyz, temp, idx, s);
+            break;
+        case 8:
+            if (t == 1024) return launch_spatial<1024, 8>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 512) return launch_spatial<512, 8>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 256) return launch_spatial<256, 8>(b, n, m, L, xyz, temp, idx, s);
+            break;
+        case 16:
+            if (t == 1024) return launch_spatial<1024, 16>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 512) return launch_spatial<512, 16>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 256) return launch_spatial<256, 16>(b, n, m, L, xyz, temp, idx, s);
+            break;
+        case 32:
+            if (t == 512) return launch_spatial<512, 32>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 256) return launch_spatial<256, 32>(b, n, m, L, xyz, temp, idx, s);
+            break;
+    }
+    return MCP_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 #ifdef MCP_FPS_DIAG
@@ -279,7 +525,10 @@ MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz
     const int bs = 1 << L;
     int rc;
     mcp_prof_begin(MCP_KERNEL_FPS, s);
-    if (bs >= 64) {
+    static const int spatial_min = env_int("MCP_FPS_SPATIAL_MIN", 1024);
+    if (n >= spatial_min && n >= 1024 && n <= 16384 && m > 1) {
+        rc = launch_spatial_any(b, n, m, L, xyz, temp, idx, s);
+    } else if (bs >= 64) {
         const int P = (n + bs - 1) / bs;
         if (bs == 1024) {
             // half-size workgroups (J = 1) from 4 points per reference thread up: fewer waves in the reduction

@@ -221,6 +221,13 @@ __device__ __forceinline__ float sub_min(float v) {
     return v;
 }
 
+template <int SUB>
+__device__ __forceinline__ float sub_max(float v) {
+    if (SUB >= 2) v = fmaxf(v, __uint_as_float(mcp_dpp<0xB1>(__float_as_uint(v))));
+    if (SUB >= 4) v = fmaxf(v, __uint_as_float(mcp_dpp<0x4E>(__float_as_uint(v))));
+    return v;
+}
+
 // SUB lanes cooperate on one query (64/SUB queries per wave): lane sub = lane % SUB scans references
 // r = sub (mod SUB) of every visited tile into its own K-list; the push threshold is the minimum of the
 // SUB K-th distances (any one list already holds K references below it, so nothing above can reach the
@@ -286,7 +293,11 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
     auto flush = [&]() {
         mcp_flush_queue<K, QS>(a, queue, lane, cnt);
         if (live) tau_own = mcp_tau_of(a[K - 1]);
+        // Push threshold shared by the query's SUB lanes.  Two valid upper bounds of the K-th distance of the union:
+        // (a) any single lane's K-th entry; (b) the largest of the lanes' (K/SUB)-th entries -- SUB * K/SUB = K
+        // candidates lie at or below it.  (b) is the tight one: a lane's own K-th entry is about the SUB*K-th overall.
         tau = sub_min<SUB>(tau_own);
+        if (SUB > 1) tau = fminf(tau, sub_max<SUB>(live ? mcp_tau_of(a[K / SUB - 1]) : -INFINITY));
         cnt = 0;
     };
 

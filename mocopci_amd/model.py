@@ -144,16 +144,17 @@ class MoCoPCI(nn.Module):
         coordinates, so the whole sampling pyramid is issued up front on the side stream."""
         p = "encoder."
         side = self.side_stream(xyz.device)
+        ready = {}
         if side is not None:
             main = torch.cuda.current_stream(xyz.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pc1 = self.fps_gather(xyz, 2048)
-                pc2 = self.fps_gather(pc1, 512)
-                pc3 = self.fps_gather(pc2, 256)
-                pc4 = self.fps_gather(pc3, 64)
-                done = torch.cuda.Event()
-                done.record(side)
+                pcs = [xyz]
+                for lvl, npoint in enumerate((2048, 512, 256, 64), start=1):
+                    pcs.append(self.fps_gather(pcs[-1], npoint))
+                    ready[lvl] = torch.cuda.Event()
+                    ready[lvl].record(side)
+            _, pc1, pc2, pc3, pc4 = pcs
             for t in (pc1, pc2, pc3, pc4):  # allocated on the side stream, consumed on the main stream
                 t.record_stream(main)
         else:
@@ -161,20 +162,27 @@ class MoCoPCI(nn.Module):
             pc2 = self.fps_gather(pc1, 512)
             pc3 = self.fps_gather(pc2, 256)
             pc4 = self.fps_gather(pc3, 64)
+
+        def need(lvl):  # the main stream waits for a level only where it first reads it
+            if side is not None:
+                main.wait_event(ready[lvl])
+
         f0 = self.conv1d_block(xyz, p + "level0_lift")
         f0 = self.pointconv(p + "level0", xyz, xyz, f0)
         f0_1 = self.conv1d_block(f0, p + "level0_1")
-        if side is not None:
-            main.wait_event(done)
+        need(1)
         f1 = self.pointconv(p + "level1", xyz, pc1, f0_1)
         f1 = self.conv1d_block(f1, p + "level1_0")
         f1_2 = self.conv1d_block(f1, p + "level1_1")
+        need(2)
         f2 = self.pointconv(p + "level2", pc1, pc2, f1_2)
         f2 = self.conv1d_block(f2, p + "level2_0")
         f2_3 = self.conv1d_block(f2, p + "level2_1")
+        need(3)
         f3 = self.pointconv(p + "level3", pc2, pc3, f2_3)
         f3 = self.conv1d_block(f3, p + "level3_0")
         f3_4 = self.conv1d_block(f3, p + "level3_1")
+        need(4)
         f4 = self.pointconv(p + "level4", pc3, pc4, f3_4)
         return [xyz, pc1, pc2, pc3, pc4], [f0, f1, f2, f3, f4]
 

@@ -31,7 +31,8 @@ def test_library_loaded_in_process():
 
 @pytest.mark.parametrize("b,n,m", [(2, 1024, 256), (2, 8192, 2048), (3, 2048, 512), (2, 512, 256), (2, 256, 64),
                                    (1, 1000, 333), (2, 100, 40), (2, 40, 17), (1, 3, 3), (1, 1024, 2048), (1, 16384, 512),
-                                   (1, 20000, 64)])
+                                   (1, 20000, 64), (1, 5000, 700), (2, 1025, 100), (1, 12000, 300), (1, 16383, 200),
+                                   (1, 14000, 150)])
 def test_fps_bit_exact(b, n, m):
     xyz = cloud(100 + n, b, n)
     want = orc.furthest_point_sample(xyz, m)
@@ -45,6 +46,23 @@ def test_fps_ties_all_equal_points():
     xyz = torch.ones(1, 777, 3)
     got = pu.furthest_point_sample(xyz.to(DEV), 9).cpu()
     assert torch.equal(got, orc.furthest_point_sample(xyz, 9)) and int(got.abs().sum()) == 0
+
+
+def test_fps_resumes_from_given_temp():
+    # the wrapper's temp buffer is an input (sampling_gpu.cu:100-112 reads it): a pre-filled temp must be honoured and the
+    # final running distances written back in the original point order, by the resident and the spatially pruned kernel
+    from mocopci_amd import pointnet2_cuda as pc
+    for n, m in ((700, 50), (6000, 400)):
+        xyz = cloud(9 + n, 2, n)
+        g = torch.Generator().manual_seed(n)
+        t0 = torch.rand(2, n, generator=g) * 30.0
+        want_idx = torch.zeros(2, m, dtype=torch.int32)
+        want_t = t0.clone()
+        orc.lib().orc_fps(orc._f(xyz), orc._f(want_t), orc._i(want_idx), 2, n, m)
+        got_idx = torch.zeros(2, m, dtype=torch.int32, device=DEV)
+        got_t = t0.to(DEV)
+        pc.furthest_point_sampling_wrapper(2, n, m, xyz.to(DEV), got_t, got_idx)
+        assert torch.equal(got_idx.cpu(), want_idx) and torch.equal(got_t.cpu(), want_t)
 
 
 def test_fps_prefix_property_full_size():
