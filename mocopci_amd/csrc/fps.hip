@@ -217,7 +217,7 @@ __device__ __forceinline__ uint32_t fps_spread6(uint32_t v) {  // 6 bits -> ever
 }
 
 template <int T, int P, bool LDS_XYZ>
-__global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, const float *__restrict__ xyz,
+__global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_idx, const float *__restrict__ xyz,
                                                         float *__restrict__ temp, int *__restrict__ idxs) {
     constexpr int W = T / 64, NS = T * P;  // NS: sort size, a power of two with n <= NS <= 16384
     extern __shared__ float4 smem_f4[];
@@ -227,6 +227,8 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, con
     float *bbox = reinterpret_cast<float *>(smem_f4) + 112;
     uint32_t *keys = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem_f4) + 512);  // [NS] during the sort
     float *sxyz = reinterpret_cast<float *>(reinterpret_cast<char *>(smem_f4) + 512);        // [n*3] afterwards
+    // [m] selected indices, flushed once at the end (a global store per iteration would sit in front of every barrier)
+    int *sidx = reinterpret_cast<int *>(reinterpret_cast<char *>(smem_f4) + lds_idx);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -296,7 +298,10 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, con
     }
     // 4. a lane takes P consecutive points of the curve; box of the valid ones
     float px[P], py[P], pz[P], pt[P];
-    uint32_t nsec[P];
+    // low key word: 14-bit tie rank above the 14-bit original index.  n >= 1024 here, so the reference block is 1024
+    // threads (L = 10) and sec(k) = bitrev10(k mod 1024) << 22 | k >> 10 compacts, order preserved, to
+    // bitrev10(k mod 1024) << 4 | k >> 10; the winner's index then needs no decoding.
+    uint32_t tag[P];
     float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
     float best = -1.0f;
 #pragma unroll
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, con
         py[p] = xyz[src * 3 + 1];
         pz[p] = xyz[src * 3 + 2];
         pt[p] = ok ? temp[src] : -INFINITY;  // never selected, never stored
-        nsec[p] = ~fps_sec((uint32_t)src, L);
+        tag[p] = ((0x3FFFu - (((__brev((uint32_t)src & 1023u) >> 22) << 4) | ((uint32_t)src >> 10))) << 14) | (uint32_t)src;
         if (ok) {
             lox = fminf(lox, px[p]); loy = fminf(loy, py[p]); loz = fminf(loz, pz[p]);
             hix = fmaxf(hix, px[p]); hiy = fmaxf(hiy, py[p]); hiz = fmaxf(hiz, pz[p]);
@@ -319,8 +324,12 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, con
     if (LDS_XYZ) {
         for (int i = tid; i < n * 3; i += T) sxyz[i] = xyz[i];
     }
-    if (tid == 0) idxs[0] = 0;
+    if (tid == 0) {
+        if (lds_idx) sidx[0] = 0;
+        else idxs[0] = 0;
+    }
     __syncthreads();
+    const f2 bx = {lox, -hix}, by = {loy, -hiy}, bz = {loz, -hiz};
 
     int old = 0;
     int s_cur = 0, s_nxt = 1;
@@ -332,14 +341,16 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, con
     for (int j = 1; j < m; ++j) {
         float x1, y1, z1;
         if (LDS_XYZ) {
-            x1 = sxyz[old * 3 + 0]; y1 = sxyz[old * 3 + 1]; z1 = sxyz[old * 3 + 2];
+            const float *c = sxyz + __umul24(old, 3);  // 24-bit multiply: full rate, old < 2^14
+            x1 = c[0]; y1 = c[1]; z1 = c[2];
         } else {
             x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
         }
         FPS_STAMP(0);  // centre read
         // exact lower bound of the lane's point distances (see the header comment); an all-padding lane has best = -1
-        const float ex = fmaxf(fmaxf(lox - x1, x1 - hix), 0.f), ey = fmaxf(fmaxf(loy - y1, y1 - hiy), 0.f),
-                    ez = fmaxf(fmaxf(loz - z1, z1 - hiz), 0.f);
+        // (lo - c, c - hi) per axis as one packed add: (lo, -hi) + (-c, c)
+        const f2 tx = bx + f2{-x1, x1}, ty = by + f2{-y1, y1}, tz = bz + f2{-z1, z1};
+        const float ex = fmaxf(fmaxf(tx.x, tx.y), 0.f), ey = fmaxf(fmaxf(ty.x, ty.y), 0.f), ez = fmaxf(fmaxf(tz.x, tz.y), 0.f);
         const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
         const bool need = lb < best;
         FPS_STAMP(1);  // box test
@@ -360,12 +371,16 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, con
             const uint32_t whi = mcp_wave_max_u32(hi);
             uint32_t bsec = 0;  // points sit in curve order, so ties inside the lane compare the keys themselves
 #pragma unroll
-            for (int p = 0; p < P; ++p) bsec = max(bsec, pt[p] == best ? nsec[p] : 0u);
+            for (int p = 0; p < P; ++p) bsec = max(bsec, pt[p] == best ? tag[p] : 0u);
             c_lo = mcp_wave_max_u32(hi == whi ? bsec : 0u);
             c_hi = whi;
         }
         FPS_STAMP(2);  // update + wave reductions
-        if (lane == 0) atomicMax(&slots[s_cur], ((unsigned long long)c_hi << 32) | c_lo);
+        if (lane == 0) {
+            // plain ds_max_u64 (atomicMax() would wrap it in a second, redundant first-active-lane election)
+            const unsigned long long key = ((unsigned long long)c_hi << 32) | c_lo;
+            asm volatile("ds_max_u64 %0, %1" ::"v"((uint32_t)(size_t)&slots[s_cur]), "v"(key) : "memory");  // low word of a flat LDS address = LDS offset
+        }
         if (tid == 0) slots[s_nxt] = 0ull;
         __syncthreads();
         FPS_STAMP(3);  // LDS atomic + barrier
@@ -373,13 +388,20 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int L, con
         const int s_new = 3 - s_cur - s_nxt;
         s_cur = s_nxt;
         s_nxt = s_new;
-        old = (int)fps_unsec(~wlo, L);
-        if (tid == 0) idxs[j] = old;
-        FPS_STAMP(4);  // slot read + decode + store
+        old = (int)(wlo & 0x3FFFu);
+        if (tid == 0) {
+            if (lds_idx) sidx[j] = old;
+            else idxs[j] = old;
+        }
+        FPS_STAMP(4);  // slot read + store
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        if (tid * P + p < n) temp[fps_unsec(~nsec[p], L)] = pt[p];
+        if (tid * P + p < n) temp[tag[p] & 0x3FFFu] = pt[p];
+    }
+    if (lds_idx) {
+        __syncthreads();
+        for (int i = tid; i < m; i += T) idxs[i] = sidx[i];
     }
 }
 
@@ -453,7 +475,12 @@ template <int T, int P>
 int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
     const size_t head = 512, key_bytes = (size_t)T * P * 4, xyz_bytes = (size_t)n * 3 * sizeof(float);
     const bool lds_xyz = head + xyz_bytes <= 160 * 1024;
-    const size_t lds = head + (lds_xyz && xyz_bytes > key_bytes ? xyz_bytes : key_bytes);
+    size_t lds = head + (lds_xyz && xyz_bytes > key_bytes ? xyz_bytes : key_bytes);
+    int lds_idx = 0;  // byte offset of the in-LDS index list, 0 = write indices straight to global memory
+    if (lds + (size_t)m * 4 <= 160 * 1024) {
+        lds_idx = (int)lds;
+        lds += (size_t)m * 4;
+    }
     static bool attr_done = false;  // benign race: the attribute is idempotent
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -462,8 +489,9 @@ int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, in
                                   160 * 1024);
         attr_done = true;
     }
-    if (lds_xyz) hipLaunchKernelGGL((fps_spatial_kernel<T, P, true>), dim3(b), dim3(T), lds, s, n, m, L, xyz, temp, idx);
-    else hipLaunchKernelGGL((fps_spatial_kernel<T, P, false>), dim3(b), dim3(T), lds, s, n, m, L, xyz, temp, idx);
+    (void)L;  // n >= 1024: the reference block size is 1024 (asserted by the caller)
+    if (lds_xyz) hipLaunchKernelGGL((fps_spatial_kernel<T, P, true>), dim3(b), dim3(T), lds, s, n, m, lds_idx, xyz, temp, idx);
+    else hipLaunchKernelGGL((fps_spatial_kernel<T, P, false>), dim3(b), dim3(T), lds, s, n, m, lds_idx, xyz, temp, idx);
     return mcp_launch_status();
 }
 
@@ -526,7 +554,7 @@ MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz
     int rc;
     mcp_prof_begin(MCP_KERNEL_FPS, s);
     static const int spatial_min = env_int("MCP_FPS_SPATIAL_MIN", 1024);
-    if (n >= spatial_min && n >= 1024 && n <= 16384 && m > 1) {
+    if (n >= spatial_min && L == 10 && n <= 16384 && m > 1) {
         rc = launch_spatial_any(b, n, m, L, xyz, temp, idx, s);
     } else if (bs >= 64) {
         const int P = (n + bs - 1) / bs;
