@@ -17,14 +17,14 @@
 //
 // Result definition (same as oracle/pointset_oracle.c:orc_knn): the K smallest under the
 // lexicographic order (distance, index), ascending; distances in the canon of common.h.
-// Keys are uint64 (ord(d) << 32 | index), so every compare-exchange is one v_cmp_lt_u64.
+// Keys are the 64-bit (distance, index) keys of topk.h: a compare-exchange is one v_min_f64 / v_max_f64 pair.
 #include "common.h"
 #include "topk.h"
 
 namespace {
 
-typedef mcp_u64 u64;
-constexpr u64 KEY_INF = MCP_KEY_INF;
+typedef mcp_key u64;  // 64-bit (distance, index) key, see topk.h
+#define KEY_INF MCP_KEY_INF
 constexpr int TILE = 256;  // reference points per LDS tile (per wave)
 
 template <int MODE>
@@ -102,9 +102,9 @@ __global__ __launch_bounds__(64 * SPLIT) void knn_small_kernel(int q, int n, int
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     if (__builtin_amdgcn_ballot_w64(d[u] < tau)) {
-                        u64 key = ((u64)mcp_ord(d[u]) << 32) | (uint32_t)(base + r0 + u);
+                        u64 key = mcp_make_key(d[u], (uint32_t)(base + r0 + u));
                         key = d[u] < tau ? key : KEY_INF;
-                        a[3] = key < a[3] ? key : a[3];
+                        a[3] = mcp_key_min(key, a[3]);
                         mcp_ce_asc(a[2], a[3]);
                         mcp_ce_asc(a[1], a[2]);
                         mcp_ce_asc(a[0], a[1]);

@@ -19,9 +19,9 @@
 
 namespace {
 
-typedef mcp_u64 u64;
+typedef mcp_key u64;  // 64-bit (distance, index) key, see topk.h
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr u64 KEY_INF = MCP_KEY_INF;
+#define KEY_INF MCP_KEY_INF
 constexpr int K = 16, QS = 16, CHK = 4, RT = 32, WAVES = 4;
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(64 * WAVES) void knn_cosine_kernel(int q, int n, in
     u64 o[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const uint32_t lo = __shfl_xor((uint32_t)a[j], 32), hi = __shfl_xor((uint32_t)(a[j] >> 32), 32);
-        o[j] = ((u64)hi << 32) | lo;
+        const uint32_t lo = __shfl_xor(mcp_key_lo(a[j]), 32), hi = __shfl_xor(mcp_key_hi(a[j]), 32);
+        o[j] = mcp_key_words(hi, lo);
     }
     mcp_merge_sorted<K, K>(a, o);
     if (!live || h) return;

@@ -23,8 +23,8 @@
 
 namespace {
 
-typedef mcp_u64 u64;
-constexpr u64 KEY_INF = MCP_KEY_INF;
+typedef mcp_key u64;  // 64-bit (distance, index) key, see topk.h
+#define KEY_INF MCP_KEY_INF
 #ifndef MCP_PRUNED_PT
 #define MCP_PRUNED_PT 64
 #endif
@@ -233,7 +233,15 @@ __device__ __forceinline__ float sub_max(float v) {
 // SUB K-th distances (any one list already holds K references below it, so nothing above can reach the
 // final K); the SUB lists are merged through DPP exchanges at the end.  More, shorter waves with smaller
 // query boxes: better pruning, latency and load balance than one lane per query.
-template <int K, int MODE, int SUB>
+#ifdef MCP_KNN_DIAG
+// diagnostic build only (never in the product library): [0] waves, [1] tiles visited, [2] flushes, [3] pushes (all lanes)
+__device__ unsigned long long g_knn_diag[4];
+#define KNN_COUNT(slot, v) do { if (lane == 0) atomicAdd(&g_knn_diag[slot], (unsigned long long)(v)); } while (0)
+#else
+#define KNN_COUNT(slot, v)
+#endif
+
+template <int K, int MODE, int SUB, int TPL>
 __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles, int kout, const float *__restrict__ query,
                                                         const int *__restrict__ qperm, const float *__restrict__ ref,
                                                         const int *__restrict__ rperm, const float *__restrict__ boxes,
@@ -263,11 +271,11 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
     const float bl0 = wave_minf(qx), bl1 = wave_minf(qy), bl2 = wave_minf(qz);
     const float bh0 = wave_maxf(qx), bh1 = wave_maxf(qy), bh2 = wave_maxf(qz);
 
-    // lower bound of the squared distance to each tile box; lane l owns tiles l, l+64, ...
-    float lb[MAX_TPL];
+    // lower bound of the squared distance to each tile box; lane l owns tiles l, l+64, ... (TPL per lane)
+    float lb[TPL];
     float m2 = fmaxf(fmaxf(fabsf(bl0), fabsf(bh0)), fmaxf(fmaxf(fabsf(bl1), fabsf(bh1)), fmaxf(fabsf(bl2), fabsf(bh2))));
 #pragma unroll
-    for (int u = 0; u < MAX_TPL; ++u) {
+    for (int u = 0; u < TPL; ++u) {
         const int t = lane + 64 * u;
         lb[u] = INFINITY;
         if (t < tiles) {
@@ -289,8 +297,13 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
     for (int j = 0; j < K; ++j) a[j] = KEY_INF;
     float tau_own = live ? INFINITY : -INFINITY;  // dead lanes never push and never hold the wave back
     float tau = tau_own;                          // shared push threshold of the query's SUB lanes
+    float taumax = INFINITY;                      // largest tau in the wave: what the next tile must beat
     int cnt = 0;
     auto flush = [&]() {
+        KNN_COUNT(2, 1);
+#ifdef MCP_KNN_DIAG
+        atomicAdd(&g_knn_diag[3], (unsigned long long)cnt);
+#endif
         mcp_flush_queue<K, QS>(a, queue, lane, cnt);
         if (live) tau_own = mcp_tau_of(a[K - 1]);
         // Push threshold shared by the query's SUB lanes.  Two valid upper bounds of the K-th distance of the union:
@@ -298,47 +311,72 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
         // candidates lie at or below it.  (b) is the tight one: a lane's own K-th entry is about the SUB*K-th overall.
         tau = sub_min<SUB>(tau_own);
         if (SUB > 1) tau = fminf(tau, sub_max<SUB>(live ? mcp_tau_of(a[K / SUB - 1]) : -INFINITY));
+        taumax = mcp_unord(mcp_wave_max_u32(mcp_ord(tau)));
         cnt = 0;
     };
 
-    for (;;) {
-        // next tile: smallest remaining bound (ties -> lowest tile id)
+    // Next unvisited tile by ascending bound, one wave reduction: the key packs the bound's ordered bits truncated to 22
+    // (rounded DOWN, so the decoded value is still a lower bound) above the inverted 10-bit tile id.  Returns -1 when
+    // every tile has been visited; marks the returned tile visited.
+    constexpr uint32_t LBQ_INF = 0xFF800000u >> 10;
+    auto next_tile = [&](float &bound) -> int {
         float mylb = lb[0];
         int myu = 0;
 #pragma unroll
-        for (int u = 1; u < MAX_TPL; ++u) {
+        for (int u = 1; u < TPL; ++u) {
             if (lb[u] < mylb) { mylb = lb[u]; myu = u; }
         }
-        const uint32_t key_hi = ~mcp_ord(mylb);                      // max-reduce of the inverted key = min bound
-        const uint32_t whi = mcp_wave_max_u32(key_hi);
         const uint32_t myt = (uint32_t)(lane + 64 * myu);
-        const uint32_t wlo = mcp_wave_max_u32(key_hi == whi ? ~myt : 0u);
-        const float minlb = mcp_unord(~whi);
-        const int t = (int)(~wlo);
-        const float taumax = mcp_unord(mcp_wave_max_u32(mcp_ord(tau)));
-        if (minlb == INFINITY) break;  // every tile visited
-        if (!(minlb <= taumax + (taumax * slack_rel + slack_abs))) break;
+        const uint32_t wkey = mcp_wave_max_u32(((~(mcp_ord(mylb) >> 10)) << 10) | (~myt & 0x3FFu));
+        const uint32_t lbq = ~(wkey >> 10) & 0x3FFFFFu;
+        if (lbq == LBQ_INF) return -1;
+        const int t = (int)(~wkey & 0x3FFu);
+        bound = mcp_unord(lbq << 10);
         if ((int)myt == t) {
 #pragma unroll
-            for (int u = 0; u < MAX_TPL; ++u)
+            for (int u = 0; u < TPL; ++u)
                 if (u == myu) lb[u] = INFINITY;
         }
+        return t;
+    };
+    // a tile's coordinates and original indices travel through registers, so the NEXT tile's global loads are in
+    // flight while the current tile is scanned (PT / 64 references per lane)
+    struct TileRegs { float x[PT / 64], y[PT / 64], z[PT / 64]; int pi[PT / 64]; };
+    auto fetch = [&](int t, TileRegs &g) {
+#pragma unroll
+        for (int u = 0; u < PT / 64; ++u) {
+            const int gi = t * PT + lane + 64 * u;
+            const bool ok = gi < n;
+            const int gg = ok ? gi : 0;
+            const float x = ref[(size_t)gg * 3 + 0], y = ref[(size_t)gg * 3 + 1], z = ref[(size_t)gg * 3 + 2];
+            g.pi[u] = ok ? rperm[gg] : 0;
+            // padding: distance evaluates to +inf in both forms
+            g.x[u] = ok ? x : (MODE == MCP_DIST_EXPANSION ? 0.f : INFINITY);
+            g.y[u] = ok ? y : 0.f;
+            g.z[u] = ok ? z : NAN;  // marks padding for the norm below
+        }
+    };
+
+    float bound = 0.f;
+    int t = next_tile(bound);  // the first tile is always visited (tau = +inf)
+    TileRegs cur, nxt;
+    if (t >= 0) fetch(t, cur);
+    KNN_COUNT(0, 1);
+    while (t >= 0) {
+        KNN_COUNT(1, 1);
+        float bound2 = 0.f;
+        const int t2 = next_tile(bound2);
+        if (t2 >= 0) fetch(t2, nxt);
         // stage the tile: coordinates + squared norm in reference order, original indices grouped per sub-lane
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < PT / 64; ++u) {
-            const int r = lane + 64 * u, gi = t * PT + r;
-            float4 v;
-            int pi = 0;
-            if (gi < n) {
-                const float x = ref[(size_t)gi * 3 + 0], y = ref[(size_t)gi * 3 + 1], z = ref[(size_t)gi * 3 + 2];
-                v = make_float4(x, y, z, mcp_sqnorm3(x, y, z));
-                pi = rperm[gi];
-            } else {
-                v = MODE == MCP_DIST_EXPANSION ? make_float4(0.f, 0.f, 0.f, INFINITY) : make_float4(INFINITY, 0.f, 0.f, 0.f);
-            }
+            const int r = lane + 64 * u;
+            const bool pad = cur.z[u] != cur.z[u];
+            float4 v = make_float4(cur.x[u], cur.y[u], pad ? 0.f : cur.z[u], 0.f);
+            v.w = pad ? (MODE == MCP_DIST_EXPANSION ? INFINITY : 0.f) : mcp_sqnorm3(v.x, v.y, v.z);
             tile[r] = v;
-            tperm[(r % SUB) * RPL + r / SUB] = pi;
+            tperm[(r % SUB) * RPL + r / SUB] = cur.pi[u];
         }
         __builtin_amdgcn_wave_barrier();
         // lane scans references sub, sub+SUB, ... ; j-th reference of the lane is tile[j*SUB + sub]
@@ -372,6 +410,10 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
         // tighten tau before the next pruning decision, but only when a queue is at least half full: a stale
         // (larger) tau is still a valid bound, it just prunes a little less
         if (__builtin_amdgcn_ballot_w64(cnt >= QS / 2)) flush();
+        // the next tile is visited only if its bound can still beat some lane's threshold
+        if (t2 < 0 || !(bound2 <= taumax + (taumax * slack_rel + slack_abs))) break;
+        t = t2;
+        cur = nxt;
     }
     flush();
     // merge the SUB lists of each query (after each round both partners hold the union's K smallest)
@@ -379,14 +421,14 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
         u64 o[K];
 #pragma unroll
         for (int j = 0; j < K; ++j)
-            o[j] = ((u64)mcp_dpp<0xB1>((uint32_t)(a[j] >> 32)) << 32) | mcp_dpp<0xB1>((uint32_t)a[j]);
+            o[j] = mcp_key_words(mcp_dpp<0xB1>(mcp_key_hi(a[j])), mcp_dpp<0xB1>(mcp_key_lo(a[j])));
         mcp_merge_sorted<K, K>(a, o);
     }
     if (SUB >= 4) {
         u64 o[K];
 #pragma unroll
         for (int j = 0; j < K; ++j)
-            o[j] = ((u64)mcp_dpp<0x4E>((uint32_t)(a[j] >> 32)) << 32) | mcp_dpp<0x4E>((uint32_t)a[j]);
+            o[j] = mcp_key_words(mcp_dpp<0x4E>(mcp_key_hi(a[j])), mcp_dpp<0x4E>(mcp_key_lo(a[j])));
         mcp_merge_sorted<K, K>(a, o);
     }
     if (!live || sub != 0) return;
@@ -396,11 +438,11 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
     mcp_store_list<K>(a, kout, oi, od);
 }
 
-template <int K, int MODE, int SUB>
-int launch_pruned_sub(int b, int q, int n, int tiles, int k, const float *query, const int *qperm, const float *ref, const int *rperm,
+template <int K, int MODE, int SUB, int TPL>
+int launch_pruned_tpl(int b, int q, int n, int tiles, int k, const float *query, const int *qperm, const float *ref, const int *rperm,
                       const float *boxes, int *idx, float *dist, hipStream_t s) {
     const size_t lds = (size_t)PrunedLds<K>::WAVE_BYTES;
-    auto kern = knn_pruned_kernel<K, MODE, SUB>;
+    auto kern = knn_pruned_kernel<K, MODE, SUB, TPL>;
     static bool attr_done = false;
     if (!attr_done) {  // lets the CU's whole 160 KB LDS count towards residency (default budget: 64 KB)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -409,6 +451,16 @@ int launch_pruned_sub(int b, int q, int n, int tiles, int k, const float *query,
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 64 / SUB), b), dim3(64), lds, s, q, n, tiles, k, query, qperm,
                        ref, rperm, boxes, idx, dist);
     return mcp_launch_status();
+}
+
+template <int K, int MODE, int SUB>
+int launch_pruned_sub(int b, int q, int n, int tiles, int k, const float *query, const int *qperm, const float *ref, const int *rperm,
+                      const float *boxes, int *idx, float *dist, hipStream_t s) {
+    // tile bounds held per lane: sized to the cloud so the per-visit argmin stays short
+    if (tiles <= 64) return launch_pruned_tpl<K, MODE, SUB, 1>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+    if (tiles <= 128) return launch_pruned_tpl<K, MODE, SUB, 2>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+    if (tiles <= 256) return launch_pruned_tpl<K, MODE, SUB, 4>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+    return launch_pruned_tpl<K, MODE, SUB, MAX_TPL>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
 }
 
 int pruned_sub_lanes() {
@@ -432,6 +484,15 @@ int launch_pruned(int b, int q, int n, int tiles, int k, const float *query, con
 }
 
 }  // namespace
+
+#ifdef MCP_KNN_DIAG
+extern "C" __attribute__((visibility("default"))) int mcp_knn_diag_read(unsigned long long *out4) {
+    hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_knn_diag), sizeof(unsigned long long) * 4);
+    unsigned long long z[4] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_diag), z, sizeof(z));
+    return (int)e;
+}
+#endif
 
 MCP_EXPORT int mcp_knn_tile_size(void) { return PT; }
 

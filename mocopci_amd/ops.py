@@ -12,6 +12,7 @@ calling `set_backend(...)`; nothing in this package imports the oracle, and HipB
 no CPU fallback (a CPU tensor raises).
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -40,8 +41,8 @@ class HipBackend:
         return out
 
     # clouds at least this large go through the Morton-sorted, box-pruned search (same results)
-    PRUNE_MIN_REFS = 4096
-    PRUNE_MIN_QUERIES = 1024
+    PRUNE_MIN_REFS = int(os.environ.get("MCP_PRUNE_MIN_REFS", "2048"))
+    PRUNE_MIN_QUERIES = int(os.environ.get("MCP_PRUNE_MIN_QUERIES", "1024"))
 
     def __init__(self):
         self._clouds = []  # [(weakref(tensor), version, sorted_cloud)], most recent last
