@@ -107,7 +107,7 @@ int mcp_knn(int b, int q, int n, int k, int dist_form, const float *query, const
  *   mcp_tile_boxes:   sorted_xyz (B,N,3) -> boxes (B,ceil(N/tile),6), tile = mcp_knn_tile_size().
  *   mcp_knn_pruned:   query_sorted (B,Q,3) with qperm (B,Q) = original row of each sorted query (NULL = identity),
  *                     ref_sorted (B,N,3) with rperm (B,N) = original index of each sorted reference, boxes as above
- *                     -> idx (B,Q,K) ORIGINAL reference indices at ORIGINAL query rows (+ dist).  4 < K <= 32, N <= 65536.
+ *                     -> idx (B,Q,K) ORIGINAL reference indices at ORIGINAL query rows (+ dist).  1 <= K <= 32, N <= 65536.
  *   mcp_build_cloud:  all of the above in one launch for N <= 16384 (bbox, isotropic Morton keys, in-LDS sort, gather,
  *                     tile boxes): xyz (B,N,3) -> sorted_xyz (B,N,3), perm (B,N) int32, boxes (B,ceil(N/tile),6). */
 int mcp_knn_tile_size(void); /* references per box tile (64): boxes arrays have ceil(N / tile) rows */
@@ -132,9 +132,12 @@ int mcp_group_rows(int b, int n, int c, int t, const float *points, const int *i
  * dense (B,N,3), sparse (B,S,3), feat (B,S,C) channel-last -> out (B,N,C);
  * 3-NN in expansion form, weights 1/max(||d||,1e-10) normalised.  idx3 (int32) and w3 (B,N,3) are
  * caller-provided outputs (the library holds no workspace); callers can reuse them for further
- * feature tensors on the same (dense, sparse) pair via mcp_interp3_apply. */
+ * feature tensors on the same (dense, sparse) pair via mcp_interp3_apply.  mcp_interp3_weights is the middle step on
+ * its own: idx3 (B,N,3) from any exact 3-NN search (mcp_knn or mcp_knn_pruned, expansion form) -> w3 (B,N,3). */
 int mcp_interp3(int b, int n, int s, int c, const float *dense, const float *sparse, const float *feat, float *out, int *idx3,
                 float *w3, mcp_stream_t stream);
+int mcp_interp3_weights(int b, int n, int s, const float *dense, const float *sparse, const int *idx3, float *w3,
+                        mcp_stream_t stream);
 int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, const int *idx3, const float *w3, float *out,
                       mcp_stream_t stream);
 

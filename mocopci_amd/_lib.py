@@ -36,6 +36,7 @@ SIGNATURES = {
     "mcp_knn_cosine": [_i] * 5 + [_p] * 6,
     "mcp_group_rows": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_interp3": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "mcp_interp3_weights": [_i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_fusion": [_i, _i, _i] + [_p] * 11,
     "mcp_cross_packed_floats": [_i],

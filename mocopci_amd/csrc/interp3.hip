@@ -84,16 +84,21 @@ MCP_EXPORT int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, 
     return mcp_launch_status();
 }
 
+MCP_EXPORT int mcp_interp3_weights(int b, int n, int s, const float *dense, const float *sparse, const int *idx3, float *w3,
+                                   mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && s > 0 && dense && sparse && idx3 && w3);
+    hipLaunchKernelGGL(interp3_weights_kernel, dim3(mcp_divup(n, BLK), b), dim3(BLK), 0, (hipStream_t)stream, n, s, dense, sparse, idx3,
+                       w3);
+    return mcp_launch_status();
+}
+
 MCP_EXPORT int mcp_interp3(int b, int n, int s, int c, const float *dense, const float *sparse, const float *feat, float *out,
                            int *idx3, float *w3, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && s > 0 && c > 0 && dense && sparse && feat && out && idx3 && w3);
     hipStream_t st = (hipStream_t)stream;
     mcp_prof_begin(MCP_KERNEL_INTERP3, st);
     int rc = mcp_knn(b, n, s, 3, MCP_DIST_EXPANSION, dense, sparse, idx3, nullptr, stream);
-    if (rc == MCP_OK) {
-        hipLaunchKernelGGL(interp3_weights_kernel, dim3(mcp_divup(n, BLK), b), dim3(BLK), 0, st, n, s, dense, sparse, idx3, w3);
-        rc = mcp_launch_status();
-    }
+    if (rc == MCP_OK) rc = mcp_interp3_weights(b, n, s, dense, sparse, idx3, w3, stream);
     if (rc == MCP_OK) rc = mcp_interp3_apply(b, n, s, c, feat, idx3, w3, out, stream);
     mcp_prof_end(MCP_KERNEL_INTERP3, st);
     return rc;

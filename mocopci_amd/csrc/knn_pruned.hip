@@ -206,7 +206,7 @@ struct PrunedLds {
 #ifndef MCP_PRUNED_QS
 #define MCP_PRUNED_QS 16
 #endif
-    static constexpr int QS = MCP_PRUNED_QS;
+    static constexpr int QS = MCP_PRUNED_QS < K ? MCP_PRUNED_QS : K;  // the merge network needs QS <= K
     static constexpr int TILE_BYTES = PT * 16;      // float4 (x,y,z,|r|^2)
     static constexpr int PERM_BYTES = PT * 4;       // original indices, stored [sub][PT/SUB]
     static constexpr int QUEUE_BYTES = QS * 64 * 8;
@@ -463,24 +463,19 @@ int launch_pruned_sub(int b, int q, int n, int tiles, int k, const float *query,
     return launch_pruned_tpl<K, MODE, SUB, MAX_TPL>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
 }
 
-int pruned_sub_lanes() {
-    // lanes per query: 4 by default (tuning hook: MCP_KNN_SUB=1|2|4)
-    static int sub = [] {
-        const char *e = getenv("MCP_KNN_SUB");
-        const int v = e ? atoi(e) : 4;
-        return (v == 1 || v == 2 || v == 4) ? v : 4;
-    }();
-    return sub;
-}
-
 template <int K, int MODE>
 int launch_pruned(int b, int q, int n, int tiles, int k, const float *query, const int *qperm, const float *ref, const int *rperm,
                   const float *boxes, int *idx, float *dist, hipStream_t s) {
-    switch (pruned_sub_lanes()) {
-        case 1: return launch_pruned_sub<K, MODE, 1>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
-        case 2: return launch_pruned_sub<K, MODE, 2>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
-        default: return launch_pruned_sub<K, MODE, 4>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
-    }
+    // 4 lanes per query (1 and 2 were measured slower at every shape of the pipeline)
+    return launch_pruned_sub<K, MODE, 4>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+}
+
+template <int MODE>
+int launch_pruned_k(int b, int q, int n, int tiles, int k, const float *query, const int *qperm, const float *ref, const int *rperm,
+                    const float *boxes, int *idx, float *dist, hipStream_t s) {
+    if (k <= 4) return launch_pruned<4, MODE>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+    if (k <= 16) return launch_pruned<16, MODE>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
+    return launch_pruned<32, MODE>(b, q, n, tiles, k, query, qperm, ref, rperm, boxes, idx, dist, s);
 }
 
 }  // namespace
@@ -531,16 +526,14 @@ MCP_EXPORT int mcp_knn_pruned(int b, int q, int n, int k, int dist_form, const f
     MCP_CHECK_ARGS(b > 0 && q > 0 && n > 0 && k > 0 && query_sorted && ref_sorted && rperm && boxes && idx);
     MCP_CHECK_ARGS(dist_form == MCP_DIST_EXPANSION || dist_form == MCP_DIST_DIRECT);
     const int tiles = (n + PT - 1) / PT;
-    if (k > 32 || k <= 4 || tiles > 64 * MAX_TPL) return MCP_ERR_UNSUPPORTED;
+    if (k > 32 || tiles > 64 * MAX_TPL) return MCP_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     mcp_prof_begin(MCP_KERNEL_KNN, s);
     int rc;
     if (dist_form == MCP_DIST_EXPANSION)
-        rc = k <= 16 ? launch_pruned<16, MCP_DIST_EXPANSION>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s)
-                     : launch_pruned<32, MCP_DIST_EXPANSION>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s);
+        rc = launch_pruned_k<MCP_DIST_EXPANSION>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s);
     else
-        rc = k <= 16 ? launch_pruned<16, MCP_DIST_DIRECT>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s)
-                     : launch_pruned<32, MCP_DIST_DIRECT>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s);
+        rc = launch_pruned_k<MCP_DIST_DIRECT>(b, q, n, tiles, k, query_sorted, qperm, ref_sorted, rperm, boxes, idx, dist, s);
     mcp_prof_end(MCP_KERNEL_KNN, s);
     return rc;
 }

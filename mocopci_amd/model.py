@@ -447,9 +447,12 @@ class MoCoPCI(nn.Module):
         # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).
         flow_src = torch.cat([frame1s[:B, 0], frame1s[:B, 1], frame1s[B:, 0]], dim=0).contiguous()      # (3B,N1,3)
         pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
-        pc1_ = torch.cat([pcs[1][:B], pcs[1][:B], pcs[1][B:]], dim=0)
         f0 = torch.cat([feats[0][:B], feats[0][:B], feats[0][B:]], dim=0)
-        up_flow = ops.backend().interp3(pc0, pc1_, flow_src)                       # (3B,N,3)
+        # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
+        # (2B rows), its rows repeated for the 3B arrangement
+        i3, w3 = ops.backend().interp3_search(pcs[0], pcs[1])
+        rep3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
+        up_flow = ops.backend().interp3_apply(flow_src, rep3(i3), rep3(w3))        # (3B,N,3)
         warped = pc0 + up_flow
         # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022)
         wf = f0 + F.adaptive_avg_pool1d(up_flow, f0.shape[-1])

@@ -86,7 +86,7 @@ class HipBackend:
         N = ref.shape[1]
         idx = torch.empty((B, Q, k), dtype=torch.int32, device=query.device)
         dist = torch.empty((B, Q, k), dtype=torch.float32, device=query.device) if return_dist else None
-        if N >= self.PRUNE_MIN_REFS and Q >= self.PRUNE_MIN_QUERIES and 4 < k <= 32 and N <= 65536:
+        if N >= self.PRUNE_MIN_REFS and Q >= self.PRUNE_MIN_QUERIES and k <= 32 and N <= 65536:
             _lib.fptr(query), _lib.fptr(ref)  # validate before building the sorted clouds
             rs, rperm, boxes = self._sorted_cloud(ref)
             qs, qperm, _ = self._sorted_cloud(query)
@@ -133,13 +133,9 @@ class HipBackend:
         """3-NN search + inverse-distance weights of UpsampleFlow (mocopci.py:1494-1498)."""
         B, N, _ = dense.shape
         S = sparse.shape[1]
-        idx3 = torch.empty((B, N, 3), dtype=torch.int32, device=dense.device)
+        idx3 = self.knn(dense, sparse, 3)  # spatially pruned for the large levels, exhaustive below
         w3 = torch.empty((B, N, 3), dtype=torch.float32, device=dense.device)
-        # the C entry point needs a feature tensor; interpolating the sparse coordinates themselves
-        # is the cheapest valid one (C=3) and its output is discarded
-        scratch = torch.empty((B, N, 3), dtype=torch.float32, device=dense.device)
-        _call("mcp_interp3", dense, B, N, S, 3, _lib.fptr(dense), _lib.fptr(sparse), _lib.fptr(sparse), _lib.fptr(scratch),
-              _lib.iptr(idx3), _lib.fptr(w3))
+        _call("mcp_interp3_weights", dense, B, N, S, _lib.fptr(dense), _lib.fptr(sparse), _lib.iptr(idx3), _lib.fptr(w3))
         return idx3, w3
 
     def interp3_apply(self, feat, idx3, w3):

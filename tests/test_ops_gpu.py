@@ -259,7 +259,8 @@ def test_compat_helpers_keep_reference_signatures():
 
 
 @pytest.mark.parametrize("q,n,k,mode,b", [(8192, 8192, 32, 0, 2), (2048, 8192, 32, 0, 2), (4096, 5000, 16, 1, 2), (1500, 16384, 32, 0, 1),
-                                          (8192, 8192, 7, 1, 1), (1024, 65536, 32, 0, 1)])
+                                          (8192, 8192, 7, 1, 1), (1024, 65536, 32, 0, 1), (8192, 2048, 3, 0, 2), (2048, 2048, 16, 0, 3),
+                                          (3000, 2500, 1, 1, 1), (2048, 2048, 4, 0, 1)])
 def test_knn_pruned_equals_bruteforce_and_oracle(q, n, k, mode, b):
     """The Morton/box-pruned search must return exactly what the exhaustive scan returns."""
     be = ops.backend()
@@ -267,12 +268,24 @@ def test_knn_pruned_equals_bruteforce_and_oracle(q, n, k, mode, b):
     query = ref if q == n else cloud(132 + q, b, q)
     rd, qd = ref.to(DEV), (None if q == n else query.to(DEV))
     qd = rd if qd is None else qd
-    gi_, gd = be.knn(qd, rd, k, mode=mode, return_dist=True)           # pruned path (n >= 4096, q >= 1024)
+    gi_, gd = be.knn(qd, rd, k, mode=mode, return_dist=True)           # pruned path (n >= 2048, q >= 1024)
     bi, bd = be.knn_bruteforce(qd, rd, k, mode=mode, return_dist=True)
     assert torch.equal(gi_, bi) and torch.equal(gd, bd)
     if n <= 16384:
         wi, wd = orc.knn(query, ref, k, mode=mode, return_dist=True)
         assert torch.equal(gi_.cpu(), wi) and torch.equal(gd.cpu(), wd)
+
+
+def test_interp3_search_pruned_route_matches_oracle():
+    # dense 8192 / sparse 2048: the 3-NN search takes the pruned kernel (K <= 4 list), weights come from mcp_interp3_weights
+    be = ops.backend()
+    dense, sparse = cloud(201, 2, 8192), cloud(202, 2, 2048)
+    feat = torch.randn(2, 2048, 9, generator=torch.Generator().manual_seed(4))
+    i3, w3 = be.interp3_search(dense.to(DEV), sparse.to(DEV))
+    wi = orc.knn(dense, sparse, 3, mode=0)
+    assert torch.equal(i3.cpu(), wi)
+    got = be.interp3_apply(feat.to(DEV), i3, w3).cpu()
+    torch.testing.assert_close(got, orc.interp3(dense, sparse, feat), rtol=1e-6, atol=1e-7)
 
 
 def test_knn_pruned_clustered_and_degenerate_clouds():
