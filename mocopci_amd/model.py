@@ -132,12 +132,15 @@ class MoCoPCI(nn.Module):
 
     def side_stream(self, device):
         """Second HIP stream for the serial FPS chains (one workgroup per batch element, latency-bound): they
-        overlap with the KNN / PointConv work of the main stream.  CPU backends run inline."""
+        overlap with the KNN / PointConv work of the main stream.  One side stream per caller stream, so forwards
+        issued on different streams stay independent.  CPU backends run inline."""
         if device.type != "cuda":
             return None
-        if getattr(self, "_side", None) is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
+        key = (device.index, torch.cuda.current_stream(device).stream_id)
+        sides = self.__dict__.setdefault("_sides", {})
+        if key not in sides:
+            sides[key] = torch.cuda.Stream(device=device)
+        return sides[key]
 
     def run_encoder(self, xyz):
         """PointConvEncoder.forward (mocopci.py:438-468), color == xyz.  The four FPS levels depend only on the

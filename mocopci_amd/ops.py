@@ -149,6 +149,9 @@ class HipBackend:
         """UpsampleFlow.forward (mocopci.py:1485-1502): dense (B,N,3), sparse (B,S,3), feat (B,S,C) -> (B,N,C)."""
         B, N, _ = dense.shape
         S, C = feat.shape[1], feat.shape[2]
+        if S >= self.PRUNE_MIN_REFS and N >= self.PRUNE_MIN_QUERIES:  # large levels: spatially pruned 3-NN search
+            idx3, w3 = self.interp3_search(dense, sparse)
+            return self.interp3_apply(feat, idx3, w3)
         idx3 = torch.empty((B, N, 3), dtype=torch.int32, device=dense.device)
         w3 = torch.empty((B, N, 3), dtype=torch.float32, device=dense.device)
         out = torch.empty((B, N, C), dtype=torch.float32, device=dense.device)
