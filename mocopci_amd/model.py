@@ -290,22 +290,28 @@ class MoCoPCI(nn.Module):
         w1, b1 = P[key]
         return self.lin(F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"]), prefix + ".fc2")
 
-    def multi_frame_att(self, prefix, x, heads=8):
-        """Multi_Frame_Att.forward (mocopci.py:551-575) batched.  x (B,5,N,C)."""
+    def multi_frame_att(self, prefix, x, heads=8, rows=None):
+        """Multi_Frame_Att.forward (mocopci.py:551-575) batched, on the INNER frames only.  The reference runs 5 frames
+        and returns frames[:, 1:-1].  Every operator in between is per frame and per point (eval-mode BatchNorm, 1x1
+        convs, PReLU) except the attention, which pairs frame f with frame 4-f of the flipped stack: the inner three pair
+        among themselves (1<->3, 2<->2), so frames 0 and 4 never reach the output and x holds frames 1..3, (B,3,N,C).
+        rows: optional int64 indices into the flattened (sample, frame) axis; the result then has shape (len(rows),1,N,.)."""
         B, Fr, N, C = x.shape
         xn = self.bn_eval(x, prefix + ".norm1", 1e-5)
         xr = torch.flip(xn, dims=[1])
         a = prefix + ".attn_feats"
-        hd = C // heads
+        if rows is not None:  # only these (sample, frame) rows are wanted: queries, residual path and MLPs shrink with them
+            x, xn, xr = (t.reshape(B * Fr, 1, N, C)[rows] for t in (x, xn, xr))
+            B, Fr = x.shape[0], 1
         o = ops.backend().attention(self.lin(xn, a + ".q").reshape(B * Fr, N, C), self.lin(xr, a + ".kv").reshape(B * Fr, N, 2 * C),
-                                    heads)                                         # (B*5,N,C)
+                                    heads)                                         # (B*3,N,C)
         o = self.lin(o.reshape(B, Fr, N, C), a + ".proj")
         xn = xn + o
         xb = self.mlp_t(prefix + ".mlp", self.bn_eval(xn, prefix + ".norm2", 1e-5))
         x = x + xb
-        xf = self.mlp_t(prefix + ".trans_block", x)                               # (B,5,N,latent)
-        frames = self.lin(xf, prefix + ".mapping_xyz")                            # (B,5,N,3)
-        return xf[:, 1:-1], frames[:, 1:-1]
+        xf = self.mlp_t(prefix + ".trans_block", x)                               # (B,3,N,latent)
+        frames = self.lin(xf, prefix + ".mapping_xyz")                            # (B,3,N,3)
+        return xf, frames
 
     def time_code(self, ts, dim, device):
         """Multiframe_Attention.time_embedding (mocopci.py:172-180): float64 python math, stored fp32."""
@@ -320,7 +326,7 @@ class MoCoPCI(nn.Module):
             self._time_cache[key] = enc.to(device)
         return self._time_cache[key]
 
-    def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc):
+    def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None):
         """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C)."""
         c1 = torch.cat([f1_0, f1_1, f1_new], dim=-1)
         c2 = torch.cat([f2_0, f2_1, f2_new], dim=-1)
@@ -351,7 +357,12 @@ class MoCoPCI(nn.Module):
         B2 = pc1.shape[0]
         fes = list(fea.reshape(R, B2, *fea.shape[1:]).unbind(0))
         n1, n2 = n1a[(R - 1) * B2:], n2a[(R - 1) * B2:]
-        x = torch.stack([n1, *fes, n2], dim=1) + time_enc                          # (B,5,N,C)
+        # mocopci.py:203 stacks [feat1_new, fe_0..2, feat2_new] + time codes as 5 frames; Multi_Frame_Att keeps only the
+        # inner three (see multi_frame_att), so the two outer frames are never built here
+        x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                            # (B,3,N,C)
+        if rows is not None:  # last level: only some frames are read, and neither the features nor n1/n2
+            _, frames = self.multi_frame_att(prefix + ".cross_block", x, rows=rows)
+            return frames[:, 0]                                                    # (len(rows),N,3)
         xf, frames = self.multi_frame_att(prefix + ".cross_block", x)              # (B,3,N,latent),(B,3,N,3)
         feat_frames = self.conv1d_block(xf, prefix + ".downsample")                # (B,3,N,C)
         return frames, n1, n2, feat_frames
@@ -443,12 +454,13 @@ class MoCoPCI(nn.Module):
         C = feats[1].shape[-1]
         te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
                        dim=0).unsqueeze(2)
-        frame1s, _, _, _ = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
-                                                     feats_o[1], fus[1], ups, te)  # (2B,3,N1,3)
-
         # l0 (mocopci.py:997-1053).  Output frames 0,1 use the forward branch (flow index i on frame 1);
-        # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).
-        flow_src = torch.cat([frame1s[:B, 0], frame1s[:B, 1], frame1s[B:, 0]], dim=0).contiguous()      # (3B,N1,3)
+        # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).  Of the level-1 flows
+        # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.
+        ar = torch.arange(B, device=dev)
+        rows = torch.cat([ar * 3, ar * 3 + 1, (ar + B) * 3])
+        flow_src = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
+                                             feats_o[1], fus[1], ups, te, rows=rows).contiguous()        # (3B,N1,3)
         pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
         f0 = torch.cat([feats[0][:B], feats[0][:B], feats[0][B:]], dim=0)
         # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
