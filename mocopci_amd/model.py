@@ -346,17 +346,32 @@ class MoCoPCI(nn.Module):
         # see the original c_feat1/c_feat2 -- so the three iterations run as one batch of 3 x (2B); feat1_new/feat2_new
         # after the loop are those of the last iteration.
         R = len(up_frames)
-        rep = lambda t: t.unsqueeze(0).expand(R, *t.shape).reshape(R * t.shape[0], *t.shape[1:])
+        B2 = pc1.shape[0]
+        dev = pc1.device
+        sel = None
+        if rows is not None:
+            # last level: flow-embedding features are read only at the selected (sample, frame) rows and at the rows their
+            # attention pairs with, (b, f) <-> (b, R-1-f); the other members of the 3 x (2B) batch are dropped
+            need = sorted({f * B2 + b for b, f in (divmod(i, R) for i in rows)} | {(R - 1 - f) * B2 + b for b, f in (divmod(i, R) for i in rows)})
+            if len(need) < R * B2:
+                sel = torch.tensor(need, device=dev)
+            rows = torch.tensor(rows, device=dev)
+        expand = lambda t: t.unsqueeze(0).expand(R, *t.shape).reshape(R * t.shape[0], *t.shape[1:])
+        rep = expand if sel is None else (lambda t: expand(t)[sel])
+        pick = (lambda t: t) if sel is None else (lambda t: t[sel])
         pc1r, pc2r = rep(pc1), rep(pc2)
         ic12, ic21 = rep(idx_c12), rep(idx_c21)
-        pc2w = self.warp(pc1r, pc2r, torch.cat(list(up_frames), dim=0))
+        pc2w = self.warp(pc1r, pc2r, pick(torch.cat(list(up_frames), dim=0)))
         n1a = self.cross(pc1r, pc2w, rep(t11_1), rep(t22_2), None, None, b + ".pos", bid_mlp, True, ic12)
         n2a = self.cross(pc2w, pc1r, rep(t11_2), rep(t22_1), None, None, b + ".pos", bid_mlp, True, ic21)
         fea = self.cross(pc1r, pc2w, self.lin(n1a, fe + ".conv1"), self.lin(n2a, fe + ".conv2"), None, None, fe + ".pos", fe_mlp,
                          False, ic12)
-        B2 = pc1.shape[0]
+        if sel is not None:  # back to the 3 x (2B) layout; the dropped members are never read
+            full = fea.new_zeros((R * B2, *fea.shape[1:]))
+            full[sel] = fea
+            fea = full
         fes = list(fea.reshape(R, B2, *fea.shape[1:]).unbind(0))
-        n1, n2 = n1a[(R - 1) * B2:], n2a[(R - 1) * B2:]
+        n1, n2 = n1a[-B2:], n2a[-B2:]  # last iteration's (unused when rows are selected)
         # mocopci.py:203 stacks [feat1_new, fe_0..2, feat2_new] + time codes as 5 frames; Multi_Frame_Att keeps only the
         # inner three (see multi_frame_att), so the two outer frames are never built here
         x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                            # (B,3,N,C)
@@ -457,8 +472,7 @@ class MoCoPCI(nn.Module):
         # l0 (mocopci.py:997-1053).  Output frames 0,1 use the forward branch (flow index i on frame 1);
         # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).  Of the level-1 flows
         # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.
-        ar = torch.arange(B, device=dev)
-        rows = torch.cat([ar * 3, ar * 3 + 1, (ar + B) * 3])
+        rows = [3 * i for i in range(B)] + [3 * i + 1 for i in range(B)] + [3 * (i + B) for i in range(B)]
         flow_src = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
                                              feats_o[1], fus[1], ups, te, rows=rows).contiguous()        # (3B,N1,3)
         pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
