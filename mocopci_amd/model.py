@@ -350,8 +350,8 @@ class MoCoPCI(nn.Module):
         dev = pc1.device
         sel = None
         if rows is not None:
-            # last level: flow-embedding features are read only at the selected (sample, frame) rows and at the rows their
-            # attention pairs with, (b, f) <-> (b, R-1-f); the other members of the 3 x (2B) batch are dropped
+            # flow-embedding features are read only at the selected (sample, frame) rows and at the rows their attention
+            # pairs with, (b, f) <-> (b, R-1-f); the other members of the 3 x (2B) batch are dropped
             need = sorted({f * B2 + b for b, f in (divmod(i, R) for i in rows)} | {(R - 1 - f) * B2 + b for b, f in (divmod(i, R) for i in rows)})
             if len(need) < R * B2:
                 sel = torch.tensor(need, device=dev)
@@ -375,12 +375,12 @@ class MoCoPCI(nn.Module):
         # mocopci.py:203 stacks [feat1_new, fe_0..2, feat2_new] + time codes as 5 frames; Multi_Frame_Att keeps only the
         # inner three (see multi_frame_att), so the two outer frames are never built here
         x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                            # (B,3,N,C)
-        if rows is not None:  # last level: only some frames are read, and neither the features nor n1/n2
+        # (the block's third output, downsample(x_f), is never read by MultiFrameEstimatier.forward in inference)
+        if rows is not None:  # only some (sample, frame) flows are read downstream
             _, frames = self.multi_frame_att(prefix + ".cross_block", x, rows=rows)
-            return frames[:, 0]                                                    # (len(rows),N,3)
-        xf, frames = self.multi_frame_att(prefix + ".cross_block", x)              # (B,3,N,latent),(B,3,N,3)
-        feat_frames = self.conv1d_block(xf, prefix + ".downsample")                # (B,3,N,C)
-        return frames, n1, n2, feat_frames
+            return frames[:, 0], n1, n2                                            # (len(rows),N,3)
+        _, frames = self.multi_frame_att(prefix + ".cross_block", x)               # (B,3,N,3)
+        return frames, n1, n2
 
     def transformer_block(self, prefix, feats, xyz, k=16):
         """TransformerBlock.forward (pointT_layer2.py:58-77): vector attention over the 16 nearest
@@ -448,16 +448,18 @@ class MoCoPCI(nn.Module):
         feats3s, frame3s = self.cross_frame_att(m + "cross_block3", xs)            # (2B,3,N3,C),(2B,3,N3,3)
         f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
 
-        def level(prefix, lvl, f_up, frames_prev, key):
-            ups = self.interp_flows(pcs[lvl], pcs[lvl + 1], frames_prev, cache, key)
-            C = feats[lvl].shape[-1]
-            te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
-                           dim=0).unsqueeze(2)                                      # (2B,5,1,C)
-            return self.multiframe_attention(prefix, pcs[lvl], pcs_o[lvl], f_up, sw(f_up), feats[lvl], fus[lvl], feats_o[lvl],
-                                             fus[lvl], ups, te)
+        # Which level-1 flows are read: l0 (below) uses, of the 2B samples x 3 frames, the forward branch's frames 0,1 and
+        # the backward branch's frame 0.  (Their flow embeddings also need each frame's attention partner f <-> 2-f, so
+        # only (backward, frame 1) is dead at level 1; the same selection one level up measured no gain and is not made.)
+        rows1 = [3 * i for i in range(B)] + [3 * i + 1 for i in range(B)] + [3 * (i + B) for i in range(B)]
 
         # l2 (mocopci.py:870-911): rows [:B] = forward direction, rows [B:] = backward direction
-        frame2s, n1_2, n2_2, feats2s = level(m + "multi_frame_up_2", 2, f_l3_2, frame3s, "32")
+        ups = self.interp_flows(pcs[2], pcs[3], frame3s, cache, "32")
+        C = feats[2].shape[-1]
+        te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
+                       dim=0).unsqueeze(2)                                          # (2B,5,1,C)
+        frame2s, n1_2, n2_2 = self.multiframe_attention(m + "multi_frame_up_2", pcs[2], pcs_o[2], f_l3_2, sw(f_l3_2), feats[2], fus[2],
+                                                        feats_o[2], fus[2], ups, te)                    # (2B,3,N2,3)
         # l2 -> l1 (mocopci.py:920-927): the forward branch upsamples (feat1_new_f -> pc1, feat2_new_f -> pc2),
         # the backward branch (feat1_new_b -> pc1, feat2_new_b -> pc2) where *_b come from the swapped call.
         f1_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n1_2[:B], n2_2[:B]], 0), cache, "21"), m + "deconv2_1")
@@ -472,9 +474,8 @@ class MoCoPCI(nn.Module):
         # l0 (mocopci.py:997-1053).  Output frames 0,1 use the forward branch (flow index i on frame 1);
         # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).  Of the level-1 flows
         # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.
-        rows = [3 * i for i in range(B)] + [3 * i + 1 for i in range(B)] + [3 * (i + B) for i in range(B)]
         flow_src = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
-                                             feats_o[1], fus[1], ups, te, rows=rows).contiguous()        # (3B,N1,3)
+                                             feats_o[1], fus[1], ups, te, rows=rows1)[0].contiguous()    # (3B,N1,3)
         pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
         f0 = torch.cat([feats[0][:B], feats[0][:B], feats[0][B:]], dim=0)
         # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
