@@ -159,7 +159,7 @@ def main():
     # roofline of the hand-written kernels timed live (hipEvents on their launch streams, inside the timed region)
     pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}
     entries = []
-    names = {"fps": "fps_resident_kernel (mcp_furthest_point_sampling)", "knn": "knn_pruned/knn_queue/knn_small kernels (mcp_knn*)",
+    names = {"fps": "fps_spatial_kernel / fps_resident_kernel (mcp_furthest_point_sampling)", "knn": "knn_pruned/knn_queue/knn_small kernels (mcp_knn*)",
              "fusion": "fusion_kernel (mcp_fusion)"}
     notes = {"fps": "algorithmic = reference streaming formulation B*(M-1)*20*N (SURVEY 8d); the kernel keeps points and temp in VGPRs, "
                     "so real HBM traffic is the compulsory B*(16N+4M); it is latency-bound on M-1 dependent iterations, one workgroup per batch element",
