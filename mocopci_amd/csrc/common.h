@@ -72,3 +72,29 @@ static inline int mcp_launch_status() {
     return e == hipSuccess ? MCP_OK : (int)e;
 }
 static inline unsigned mcp_divup(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// Raw max / min / relu.  fmaxf()/fminf() first canonicalise any operand the compiler cannot prove quiet (MFMA results,
+// loads, DPP outputs): an extra v_max_f32 x,x per operand.  The kernels' values are never signalling NaNs, so the
+// hot loops use the bare instructions.  NEVER feed these an MFMA result directly: the compiler does not see into the
+// asm, so it inserts none of the wait states an MFMA -> VALU read needs (measured: wrong results); pass MFMA outputs
+// through a compiler-visible instruction first.
+__device__ __forceinline__ float mcp_max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float mcp_min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float mcp_max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float mcp_relu_raw(float a) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+    return r;
+}

@@ -27,20 +27,56 @@ constexpr int KNB = 32;
 constexpr float SLOPE = 0.1f;  // pointconv_util.py:10
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * SLOPE; }
+// LeakyReLU with 0 < slope < 1 is max(v, slope*v): two instructions, same value for every finite v (and for +-0)
+__device__ __forceinline__ float leaky(float v) { return mcp_max_raw(v, v * SLOPE); }
 
 template <int CTRL>
 __device__ __forceinline__ float dppf(float v) {
     return __uint_as_float(mcp_dpp<CTRL>(__float_as_uint(v)));
 }
-// max over the 32 lanes that share lane>>5
-__device__ __forceinline__ float half_max(float v) {
-    v = fmaxf(v, dppf<0xB1>(v));
-    v = fmaxf(v, dppf<0x4E>(v));
-    v = fmaxf(v, dppf<0x141>(v));
-    v = fmaxf(v, dppf<0x140>(v));
-    return fmaxf(v, __shfl_xor(v, 16));
+// dst <- max(src0 read through the DPP pattern, src1) in the lanes of the enabled banks; the other lanes keep dst.
+// Raw instruction: fmaxf() would first canonicalise both operands (two extra v_max each), and the values here are
+// never NaN-signalling.  s_nop 1 covers the two wait states a DPP read needs after a VALU write of its source.
+#define MCP_MAX_DPP(dst, src0, src1, CTRL)                                                                              \
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 " CTRL : "+v"(dst) : "v"(src0), "v"(src1))
+
+// Maximum over the 32 neighbours (the 32 lanes that share lane>>5) of all 16 accumulator registers, as a reduce-scatter:
+// every butterfly step halves the number of live registers instead of reducing all of them everywhere (16 registers x
+// 5 steps before; 16+8+4+3+1 instructions now).  Step over lane bit 4: v_permlane16_swap exchanges the odd rows of one
+// register with the even rows of another, so one max folds two registers into one.  Bits 3 and 2: DPP row_ror:8 /
+// row_half_mirror with bank masks choose per 4-lane bank which register of the pair is kept.  Bit 1 needs a select,
+// bit 0 a plain exchange.  Result: lane l holds the maximum of register r(l) = 8*b4 + 4*b3 + 2*b2 + b1 (b_k = bit k
+// of l), duplicated in lanes l and l^1.
+__device__ __forceinline__ float scatter_max(const f32x16 &acc, int lane) {
+    float v8[8], v4[4], v2[2];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[r]), __float_as_uint(acc[r + 8]), false, false);
+        const float a = __uint_as_float(sw[0]), b = __uint_as_float(sw[1]);
+        asm("v_max_f32 %0, %1, %2" : "=v"(v8[r]) : "v"(a), "v"(b));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // banks 0,1 (bit 3 clear) keep r, banks 2,3 keep r+4
+        float d = v8[r + 4];
+        MCP_MAX_DPP(d, v8[r], v8[r], "row_ror:8 row_mask:0xf bank_mask:0x3");
+        MCP_MAX_DPP(d, v8[r + 4], d, "row_ror:8 row_mask:0xf bank_mask:0xc");
+        v4[r] = d;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {  // banks 0,2 (bit 2 clear) keep r, banks 1,3 keep r+2; lane i pairs with 7-i of its half row
+        float d = v4[r + 2];
+        MCP_MAX_DPP(d, v4[r], v4[r], "row_half_mirror row_mask:0xf bank_mask:0x5");
+        MCP_MAX_DPP(d, v4[r + 2], d, "row_half_mirror row_mask:0xf bank_mask:0xa");
+        v2[r] = d;
+    }
+    const bool b1 = (lane & 2) != 0;
+    float keep = b1 ? v2[1] : v2[0];
+    const float send = b1 ? v2[0] : v2[1];
+    MCP_MAX_DPP(keep, send, keep, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    MCP_MAX_DPP(keep, keep, keep, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    return keep;
 }
+__device__ __forceinline__ int scatter_reg(int lane) { return ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1); }
 
 template <int D>
 struct CrossLds {
@@ -98,38 +134,63 @@ __global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : 2)) void cross_kernel(lo
     const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     const float4 *wq = reinterpret_cast<const float4 *>(lds + L::OFF_W);
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
-        const long long bb = p / n1;
-        const int id = idx[p * KNB + col];
+    // Software pipeline over the wave's points: the neighbour index of point i+2 and the gathered rows of point i+1 are
+    // in flight while the D x D layer of point i runs on the MFMA pipe (the row registers are free again once layer 1
+    // has consumed them), so the idx -> gather -> MFMA latency chain is paid once per wave, not once per point.
+    const long long stride = (long long)gridDim.x * WAVES;
+    long long p = (long long)blockIdx.x * WAVES + wave;
+    float in0 = 0.f, in1 = 0.f;
+    // gathered points2 row and (D = 64 only: at D = 128 it would spill) points1 row, both in accumulator layout
+    constexpr bool PRE_A = D <= 64;
+    float4 ra[PRE_A ? T : 1][4], rg[T][4];
+    auto fetch = [&](long long pp, int id) {
+        const long long bb = pp / n1;
         const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
-        const float dx = q2[0] - xyz1[p * 3 + 0], dy = q2[1] - xyz1[p * 3 + 1], dz = q2[2] - xyz1[p * 3 + 2];
-        const float in0 = h ? dy : dx, in1 = h ? 1.0f : dz;
+        const float dx = q2[0] - xyz1[pp * 3 + 0], dy = q2[1] - xyz1[pp * 3 + 1], dz = q2[2] - xyz1[pp * 3 + 2];
+        in0 = h ? dy : dx;
+        in1 = h ? 1.0f : dz;
         const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)bb * n2 + id) * D);
-        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + p * D);
-
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + pp * D);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // channels 32t + 8g + 4h .. +3  ->  registers 4g .. 4g+3
+                if (PRE_A) ra[t][g] = row1[(32 * t + 8 * g + 4 * h) >> 2];
+                rg[t][g] = row2[(32 * t + 8 * g + 4 * h) >> 2];
+            }
+    };
+    long long pn = p + stride;
+    int idn = 0;
+    if (p < total) {
+        fetch(p, idx[p * KNB + col]);
+        if (pn < total) idn = idx[pn * KNB + col];
+    }
+    for (; p < total; p = pn, pn += stride) {
         f32x16 x0[T];
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + p * D);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             f32x16 acc;
-            float4 g2[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {  // channels 32t + 8g + 4h .. +3  ->  registers 4g .. 4g+3
-                const float4 a = row1[(32 * t + 8 * g + 4 * h) >> 2];
-                g2[g] = row2[(32 * t + 8 * g + 4 * h) >> 2];
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = PRE_A ? ra[t][g] : row1[(32 * t + 8 * g + 4 * h) >> 2];
                 acc[4 * g + 0] = a.x; acc[4 * g + 1] = a.y; acc[4 * g + 2] = a.z; acc[4 * g + 3] = a.w;
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L::OFF_POS + (t * 2 + 0) * 64 + lane], in0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L::OFF_POS + (t * 2 + 1) * 64 + lane], in1, acc, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                acc[4 * g + 0] = leaky(acc[4 * g + 0] + g2[g].x);
-                acc[4 * g + 1] = leaky(acc[4 * g + 1] + g2[g].y);
-                acc[4 * g + 2] = leaky(acc[4 * g + 2] + g2[g].z);
-                acc[4 * g + 3] = leaky(acc[4 * g + 3] + g2[g].w);
+                acc[4 * g + 0] = leaky(acc[4 * g + 0] + rg[t][g].x);
+                acc[4 * g + 1] = leaky(acc[4 * g + 1] + rg[t][g].y);
+                acc[4 * g + 2] = leaky(acc[4 * g + 2] + rg[t][g].z);
+                acc[4 * g + 3] = leaky(acc[4 * g + 3] + rg[t][g].w);
             }
             x0[t] = acc;
         }
-        float4 *orow = reinterpret_cast<float4 *>(out + p * D);
+        if (pn < total) {
+            fetch(pn, idn);
+            if (pn + stride < total) idn = idx[(pn + stride) * KNB + col];
+        }
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             f32x16 acc;
@@ -144,13 +205,8 @@ __global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : 2)) void cross_kernel(lo
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x0[tin][r0 + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x0[tin][r0 + 3], acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = half_max(leaky(acc[r]));  // leaky is monotone: max commutes
-            if (col == 0) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    orow[(32 * t + 8 * g + 4 * h) >> 2] = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-            }
+            const float m = leaky(scatter_max(acc, lane));  // leaky is monotone: it commutes with the max
+            if ((lane & 1) == 0) out[p * D + 32 * t + chan_of(scatter_reg(lane), h)] = m;
         }
     }
 }
@@ -167,7 +223,9 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
     }
     // at least 8 points per wave so the weight staging is amortised
     const long long want = (total + WAVES * 8 - 1) / (WAVES * 8);
-    const unsigned grid = (unsigned)max(1LL, min(want, (long long)(lds > 40 * 1024 ? 512 : 1024)));
+    // persistent-style grid = exactly the resident slots (256 CUs x 3 or 2 workgroups, see __launch_bounds__): a larger
+    // grid leaves a partly filled second round of workgroups
+    const unsigned grid = (unsigned)max(1LL, min(want, (long long)(D == 64 ? 768 : 512)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out);
     return mcp_launch_status();
 }
