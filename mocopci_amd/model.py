@@ -269,14 +269,21 @@ class MoCoPCI(nn.Module):
         xn = self.bn_eval(x, prefix + ".norm1", 1e-5)
         xr = torch.flip(xn, dims=[1])
         a = prefix + ".attn_feats"
-        q = self.lin(xn, a + ".q").reshape(B * Fr, N, 4, C).permute(0, 2, 1, 3)
-        kv = self.lin(xr, a + ".kv").reshape(B * Fr, N, 2, 4, C).permute(2, 0, 3, 1, 4)
-        o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=C ** -0.5)      # (B*2,4,N,C)
-        o = self.lin(o.reshape(B, Fr, 4, N, C).sum(dim=1), a + ".proj")           # (B,4,N,C)
+        # head slot 0 is the dropped one and nothing after the attention mixes slots: project only heads 1..3
+        key = ("cfa_heads", prefix)
+        if key not in P:
+            wq, bq, wkv, bkv = self.W(a + ".q"), self.Bv(a + ".q"), self.W(a + ".kv"), self.Bv(a + ".kv")
+            sl = lambda t: None if t is None else torch.cat([t[C:4 * C], t[5 * C:8 * C]], dim=0).contiguous()
+            P[key] = (wq[C:].contiguous(), None if bq is None else bq[C:].contiguous(), sl(wkv), sl(bkv))
+        wq, bq, wkv, bkv = P[key]
+        q = F.linear(xn, wq, bq).reshape(B * Fr, N, 3, C).permute(0, 2, 1, 3)
+        kv = F.linear(xr, wkv, bkv).reshape(B * Fr, N, 2, 3, C).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=C ** -0.5)      # (B*2,3,N,C)
+        o = self.lin(o.reshape(B, Fr, 3, N, C).sum(dim=1), a + ".proj")           # (B,3,N,C)
         t = prefix + ".trans_block_2"
         xa = self.lin(F.prelu(self.lin(o, t + ".fc1"), P[t + ".act.weight"]), t + ".fc2")
         frames = self.lin(xa, prefix + ".mapping_xyz")
-        return xa[:, 1:], frames[:, 1:]                                           # (B,3,N,C), (B,3,N,3)
+        return xa, frames                                                         # (B,3,N,C), (B,3,N,3)
 
     def mlp_t(self, prefix, x):
         """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2.  The depthwise k=1 conv is a
@@ -312,6 +319,20 @@ class MoCoPCI(nn.Module):
         xf = self.mlp_t(prefix + ".trans_block", x)                               # (B,3,N,latent)
         frames = self.lin(xf, prefix + ".mapping_xyz")                            # (B,3,N,3)
         return xf, frames
+
+    def area_matrix(self, n_in, n_out, device):
+        """F.interpolate(mode="area") = adaptive average pooling along the last axis, as an (n_in, n_out) matrix: output j
+        averages inputs floor(j*n_in/n_out) .. ceil((j+1)*n_in/n_out)-1.  (3 -> 32: one or two inputs per output, so the
+        product is the same sum of the same rounded terms.)"""
+        key = ("area", n_in, n_out, str(device))
+        self.__dict__.setdefault("_time_cache", {})
+        if key not in self._time_cache:
+            m = torch.zeros(n_in, n_out)
+            for j in range(n_out):
+                lo, hi = (j * n_in) // n_out, -((-(j + 1) * n_in) // n_out)
+                m[lo:hi, j] = 1.0 / (hi - lo)
+            self._time_cache[key] = m.to(device)
+        return self._time_cache[key]
 
     def time_code(self, ts, dim, device):
         """Multiframe_Attention.time_embedding (mocopci.py:172-180): float64 python math, stored fp32."""
@@ -485,7 +506,7 @@ class MoCoPCI(nn.Module):
         up_flow = ops.backend().interp3_apply(flow_src, rep3(i3), rep3(w3))        # (3B,N,3)
         warped = pc0 + up_flow
         # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022)
-        wf = f0 + F.adaptive_avg_pool1d(up_flow, f0.shape[-1])
+        wf = f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev)
         side = self.side_stream(dev)
         if side is not None:
             main = torch.cuda.current_stream(dev)
