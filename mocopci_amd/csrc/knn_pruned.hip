@@ -18,6 +18,8 @@
 // At N=8192 a wave scans ~1300 of the 8192 references (64-point tiles measured 5-7 % faster than 128/256).
 #include <stdlib.h>
 
+#include <rocprim/block/block_radix_sort.hpp>
+
 #include "common.h"
 #include "topk.h"
 
@@ -92,17 +94,29 @@ __global__ __launch_bounds__(64) void tile_box_kernel(int n, int tiles, const fl
     }
 }
 
-// ---- fused cloud builder: bbox -> Morton keys -> LDS bitonic sort -> gather -> tile boxes ---------------------
-// One workgroup per batch element (N <= 16384: the (key << 32 | index) array lives in LDS).
+// ---- fused cloud builder: bbox -> Morton keys -> block radix sort -> gather -> tile boxes -----------------------
+// One workgroup per batch element (N <= 16384).  The sort is rocPRIM's block_radix_sort on (30-bit code, index) pairs
+// held in registers (IPT per thread): stable, so points of one cell stay in index order -- the same permutation as
+// sorting (code << 32 | index).
 constexpr int BT = 1024;
-__global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int npow2, int tiles, const float *__restrict__ xyz,
+template <int IPT>
+struct CloudSort {
+    using Sort = rocprim::block_radix_sort<uint32_t, BT, IPT, uint32_t>;
+    union Lds {
+        typename Sort::storage_type sort;
+        uint32_t order[BT * IPT];  // sorted original indices, for the tile boxes
+    };
+};
+
+template <int IPT>
+__global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int tiles, const float *__restrict__ xyz,
                                                          float *__restrict__ sorted_xyz, int *__restrict__ perm,
                                                          float *__restrict__ boxes) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dyn[];
-    // one dynamic LDS block: [0,512) reduction scratch + bbox, then the npow2 keys
+    // dynamic LDS: [0,512) reduction scratch + bbox, then the sort storage / index list
     float(*red)[BT / 64] = reinterpret_cast<float(*)[BT / 64]>(dyn);     // [6][16] floats = 384 B
     float *bbox = reinterpret_cast<float *>(dyn) + 6 * (BT / 64);          // [6]
-    unsigned long long *keys = dyn + 64;                                   // 512 B in
+    typename CloudSort<IPT>::Lds &lds = *reinterpret_cast<typename CloudSort<IPT>::Lds *>(dyn + 64);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     xyz += (size_t)b * n * 3;
     sorted_xyz += (size_t)b * n * 3;
@@ -132,9 +146,13 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int npow2, int t
     }
     __syncthreads();
     const float ext = fmaxf(fmaxf(bbox[3] - bbox[0], bbox[4] - bbox[1]), bbox[5] - bbox[2]);
-    // 2. keys: isotropic 10-bit cells (LiDAR clouds are flat: per-axis scaling would slice them into thin slabs)
-    for (int i = tid; i < npow2; i += BT) {
-        unsigned long long k = ~0ull;
+    // 2. keys: isotropic 10-bit cells (LiDAR clouds are flat: per-axis scaling would slice them into thin slabs);
+    //    thread t holds points t*IPT .. t*IPT+IPT-1, padding sorts last (bit 30)
+    uint32_t keys[IPT], vals[IPT];
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) {
+        const int i = tid * IPT + u;
+        uint32_t k = 0x40000000u;
         if (i < n) {
             uint32_t c[3];
 #pragma unroll
@@ -143,38 +161,33 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int npow2, int t
                 t = fminf(fmaxf(t * 1024.f, 0.f), 1023.f);
                 c[a] = (uint32_t)t;
             }
-            const uint32_t code = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
-            k = ((unsigned long long)code << 32) | (uint32_t)i;
+            k = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
         }
-        keys[i] = k;
+        keys[u] = k;
+        vals[u] = (uint32_t)i;
+    }
+    // 3. stable radix sort of the (code, index) pairs over bits 0..30
+    typename CloudSort<IPT>::Sort().sort(keys, vals, lds.sort, 0, 31);
+    __syncthreads();
+    // 4. permutation + sorted coordinates (sorted position s = tid*IPT + u)
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) {
+        const int s = tid * IPT + u;
+        lds.order[s] = vals[u];
+        if (s < n) {
+            const int src = (int)vals[u];
+            perm[s] = src;
+            sorted_xyz[(size_t)s * 3 + 0] = xyz[(size_t)src * 3 + 0];
+            sorted_xyz[(size_t)s * 3 + 1] = xyz[(size_t)src * 3 + 1];
+            sorted_xyz[(size_t)s * 3 + 2] = xyz[(size_t)src * 3 + 2];
+        }
     }
     __syncthreads();
-    // 3. bitonic sort of (code, index) in LDS
-    for (int k = 2; k <= npow2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < npow2 / 2; p += BT) {
-                const int i = 2 * p - (p & (j - 1));  // element with bit j clear
-                const int l = i + j;
-                const unsigned long long x = keys[i], y = keys[l];
-                const bool up = (i & k) == 0;
-                if ((y < x) == up) { keys[i] = y; keys[l] = x; }
-            }
-            __syncthreads();
-        }
-    }
-    // 4. permutation + sorted coordinates
-    for (int i = tid; i < n; i += BT) {
-        const int src = (int)(uint32_t)keys[i];
-        perm[i] = src;
-        sorted_xyz[(size_t)i * 3 + 0] = xyz[(size_t)src * 3 + 0];
-        sorted_xyz[(size_t)i * 3 + 1] = xyz[(size_t)src * 3 + 1];
-        sorted_xyz[(size_t)i * 3 + 2] = xyz[(size_t)src * 3 + 2];
-    }
     // 5. one box per tile of PT sorted points (a wave per tile)
     for (int t = wave; t < tiles; t += BT / 64) {
         float tl[3] = {INFINITY, INFINITY, INFINITY}, th[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int i = t * PT + lane; i < min(n, (t + 1) * PT); i += 64) {
-            const int src = (int)(uint32_t)keys[i];
+            const int src = (int)lds.order[i];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float v = xyz[(size_t)src * 3 + a];
@@ -192,6 +205,19 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int npow2, int t
             o[0] = tl[0]; o[1] = tl[1]; o[2] = tl[2]; o[3] = th[0]; o[4] = th[1]; o[5] = th[2];
         }
     }
+}
+
+template <int IPT>
+int launch_build_cloud(int b, int n, int tiles, const float *xyz, float *sorted_xyz, int *perm, float *boxes, hipStream_t s) {
+    auto kern = build_cloud_kernel<IPT>;
+    const size_t lds = 512 + sizeof(typename CloudSort<IPT>::Lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(b), dim3(BT), lds, s, n, tiles, xyz, sorted_xyz, perm, boxes);
+    return mcp_launch_status();
 }
 
 // ---- the search ------------------------------------------------------------------------------
@@ -507,17 +533,13 @@ MCP_EXPORT int mcp_tile_boxes(int b, int n, const float *sorted_xyz, float *boxe
 MCP_EXPORT int mcp_build_cloud(int b, int n, const float *xyz, float *sorted_xyz, int *perm, float *boxes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && sorted_xyz && perm && boxes);
     if (n > 16384) return MCP_ERR_UNSUPPORTED;  // larger clouds: mcp_morton_codes + an external sort + mcp_tile_boxes
-    int npow2 = 1;
-    while (npow2 < n) npow2 <<= 1;
     const int tiles = (n + PT - 1) / PT;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(build_cloud_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(build_cloud_kernel, dim3(b), dim3(BT), (size_t)npow2 * 8 + 512, (hipStream_t)stream, n, npow2, tiles, xyz, sorted_xyz,
-                       perm, boxes);
-    return mcp_launch_status();
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= BT) return launch_build_cloud<1>(b, n, tiles, xyz, sorted_xyz, perm, boxes, s);
+    if (n <= 2 * BT) return launch_build_cloud<2>(b, n, tiles, xyz, sorted_xyz, perm, boxes, s);
+    if (n <= 4 * BT) return launch_build_cloud<4>(b, n, tiles, xyz, sorted_xyz, perm, boxes, s);
+    if (n <= 8 * BT) return launch_build_cloud<8>(b, n, tiles, xyz, sorted_xyz, perm, boxes, s);
+    return launch_build_cloud<16>(b, n, tiles, xyz, sorted_xyz, perm, boxes, s);
 }
 
 MCP_EXPORT int mcp_knn_pruned(int b, int q, int n, int k, int dist_form, const float *query_sorted, const int *qperm,

@@ -23,3 +23,6 @@ for n in (2048, 512):
             print(f"   pruned incl. 2 builds {tot:8.1f} us   search only {cached:8.1f} us", end="")
         print()
     print(f"n={n} build_cloud {t(lambda: be._sorted_cloud(a.clone())):8.1f} us (incl clone)")
+for n in (8192, 16384, 1000):
+    c = (torch.rand(24, n, 3, device="cuda") * 80 - 40).contiguous()
+    print(f"n={n} build_cloud x24 {t(lambda: be._sorted_cloud(c.clone())):8.1f} us (incl clone)")
