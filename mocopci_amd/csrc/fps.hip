@@ -18,6 +18,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <rocprim/block/block_radix_sort.hpp>
+
 #include "common.h"
 
 // workgroup shape for 4 / 8 points per reference thread (T = 1024 >> J, P points per physical thread)
@@ -216,16 +218,19 @@ __device__ __forceinline__ uint32_t fps_spread6(uint32_t v) {  // 6 bits -> ever
     return r;
 }
 
+template <int T, int P>
+using SpatialSort = rocprim::block_radix_sort<uint32_t, T, P>;
+
 template <int T, int P, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_idx, const float *__restrict__ xyz,
                                                         float *__restrict__ temp, int *__restrict__ idxs) {
-    constexpr int W = T / 64, NS = T * P;  // NS: sort size, a power of two with n <= NS <= 16384
+    constexpr int W = T / 64;  // T * P >= n points are keyed and sorted (a power of two, <= 16384)
     extern __shared__ float4 smem_f4[];
     // header (512 B): [0,24) rotating max slots, [64,448) bbox reduction scratch, [448,472) cloud bbox
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_f4);
     float(*red)[16] = reinterpret_cast<float(*)[16]>(reinterpret_cast<float *>(smem_f4) + 16);
     float *bbox = reinterpret_cast<float *>(smem_f4) + 112;
-    uint32_t *keys = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem_f4) + 512);  // [NS] during the sort
+    char *sort_lds = reinterpret_cast<char *>(smem_f4) + 512;                                  // rocPRIM sort storage first
     float *sxyz = reinterpret_cast<float *>(reinterpret_cast<char *>(smem_f4) + 512);        // [n*3] afterwards
     // [m] selected indices, flushed once at the end (a global store per iteration would sit in front of every barrier)
     int *sidx = reinterpret_cast<int *>(reinterpret_cast<char *>(smem_f4) + lds_idx);
@@ -236,16 +241,20 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
     temp += (size_t)blockIdx.x * n;
     idxs += (size_t)blockIdx.x * m;
 
-    // 1. bounding box of the cloud
+    // 1. bounding box of the cloud; a thread reads the P points it will key (blocked arrangement) once
+    uint32_t keys[P];
     {
+        float qx[P], qy[P], qz[P];
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int i = tid; i < n; i += T) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float v = xyz[(size_t)i * 3 + a];
-                lo[a] = fminf(lo[a], v);
-                hi[a] = fmaxf(hi[a], v);
-            }
+        for (int u = 0; u < P; ++u) {
+            const int i = tid * P + u;
+            const int ii = i < n ? i : 0;
+            qx[u] = xyz[(size_t)ii * 3 + 0];
+            qy[u] = xyz[(size_t)ii * 3 + 1];
+            qz[u] = xyz[(size_t)ii * 3 + 2];
+            lo[0] = fminf(lo[0], qx[u]); lo[1] = fminf(lo[1], qy[u]); lo[2] = fminf(lo[2], qz[u]);
+            hi[0] = fmaxf(hi[0], qx[u]); hi[1] = fmaxf(hi[1], qy[u]); hi[2] = fmaxf(hi[2], qz[u]);
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -261,41 +270,20 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
             bbox[tid] = v;
         }
         __syncthreads();
-    }
-    // 2. keys: 18-bit Morton code of isotropic cells (LiDAR clouds are flat) above the 14-bit point index
-    {
+        // 2. keys: 18-bit Morton code of isotropic cells (LiDAR clouds are flat) above the 14-bit point index
         const float ext = fmaxf(fmaxf(bbox[3] - bbox[0], bbox[4] - bbox[1]), bbox[5] - bbox[2]);
-        for (int i = tid; i < NS; i += T) {
-            uint32_t k = 0xFFFFFFFFu;
-            if (i < n) {
-                uint32_t c[3];
+        const float inv = ext > 0.f ? 64.f / ext : 0.f;  // cell assignment only orders the points: any monotone map will do
+        const float b0 = bbox[0], b1 = bbox[1], b2 = bbox[2];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    float t = ext > 0.f ? (xyz[(size_t)i * 3 + a] - bbox[a]) / ext : 0.f;
-                    t = fminf(fmaxf(t * 64.f, 0.f), 63.f);
-                    c[a] = (uint32_t)t;
-                }
-                k = ((fps_spread6(c[0]) | (fps_spread6(c[1]) << 1) | (fps_spread6(c[2]) << 2)) << 14) | (uint32_t)i;
-            }
-            keys[i] = k;
-        }
-        __syncthreads();
-    }
-    // 3. bitonic sort in LDS
-    for (int k = 2; k <= NS; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-            for (int u = 0; u < P / 2; ++u) {
-                const int p = tid + T * u;
-                const int i = 2 * p - (p & (j - 1));
-                const int l = i + j;
-                const uint32_t x = keys[i], y = keys[l];
-                const bool up = (i & k) == 0;
-                if ((y < x) == up) { keys[i] = y; keys[l] = x; }
-            }
-            __syncthreads();
+        for (int u = 0; u < P; ++u) {
+            const int i = tid * P + u;
+            const uint32_t c0 = (uint32_t)fminf(fmaxf((qx[u] - b0) * inv, 0.f), 63.f), c1 = (uint32_t)fminf(fmaxf((qy[u] - b1) * inv, 0.f), 63.f),
+                           c2 = (uint32_t)fminf(fmaxf((qz[u] - b2) * inv, 0.f), 63.f);
+            keys[u] = i < n ? ((fps_spread6(c0) | (fps_spread6(c1) << 1) | (fps_spread6(c2) << 2)) << 14) | (uint32_t)i : 0xFFFFFFFFu;
         }
     }
+    // 3. block radix sort of the keys (rocPRIM, four 8-bit passes); thread t ends up with sorted positions t*P .. t*P+P-1
+    SpatialSort<T, P>().sort(keys, *reinterpret_cast<typename SpatialSort<T, P>::storage_type *>(sort_lds));
     // 4. a lane takes P consecutive points of the curve; box of the valid ones
     float px[P], py[P], pz[P], pt[P];
     // low key word: 14-bit tie rank above the 14-bit original index.  n >= 1024 here, so the reference block is 1024
@@ -308,7 +296,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
     for (int p = 0; p < P; ++p) {
         const int s = tid * P + p;
         const bool ok = s < n;  // the n real keys sort in front of the padding
-        const int src = ok ? (int)(keys[s] & 0x3FFFu) : 0;
+        const int src = ok ? (int)(keys[p] & 0x3FFFu) : 0;
         px[p] = xyz[src * 3 + 0];
         py[p] = xyz[src * 3 + 1];
         pz[p] = xyz[src * 3 + 2];
@@ -320,7 +308,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
             best = fmaxf(best, pt[p]);
         }
     }
-    __syncthreads();  // keys are dead: the region is reused for the coordinates
+    __syncthreads();  // the sort storage is dead: the region is reused for the coordinates
     if (LDS_XYZ) {
         for (int i = tid; i < n * 3; i += T) sxyz[i] = xyz[i];
     }
@@ -338,6 +326,9 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
     unsigned long long t_prev = 0;
     FPS_STAMP(7);
 #endif
+    // the loop below is a pure latency chain: its placement relative to the instruction-fetch lines is worth ~2 % (measured),
+    // so it starts on a 64-byte boundary
+    asm volatile(".p2align 6");
     for (int j = 1; j < m; ++j) {
         float x1, y1, z1;
         if (LDS_XYZ) {
@@ -473,7 +464,7 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
 
 template <int T, int P>
 int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
-    const size_t head = 512, key_bytes = (size_t)T * P * 4, xyz_bytes = (size_t)n * 3 * sizeof(float);
+    const size_t head = 512, key_bytes = sizeof(typename SpatialSort<T, P>::storage_type), xyz_bytes = (size_t)n * 3 * sizeof(float);
     const bool lds_xyz = head + xyz_bytes <= 160 * 1024;
     size_t lds = head + (lds_xyz && xyz_bytes > key_bytes ? xyz_bytes : key_bytes);
     int lds_idx = 0;  // byte offset of the in-LDS index list, 0 = write indices straight to global memory

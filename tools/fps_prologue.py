@@ -1,0 +1,15 @@
+import os, sys, statistics, torch
+sys.path.insert(0, '/root/repo')
+from mocopci_amd import ops, synth
+be = ops.backend()
+x1, x2, _ = synth.make_batch(2, 8, 8192, device="cuda")
+a = torch.cat([x1, x2]).transpose(1, 2).contiguous()
+def t(fn, reps=9):
+    fn(); torch.cuda.synchronize(); v = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(True), torch.cuda.Event(True)
+        s.record(); fn(); e.record(); torch.cuda.synchronize(); v.append(s.elapsed_time(e) * 1e3)
+    return statistics.median(v)
+for n in (8192, 2048):
+    c = a[:, :n].contiguous()
+    print(n, "m=2", t(lambda: be.fps(c, 2)), "m=34", t(lambda: be.fps(c, 34)), "m=66", t(lambda: be.fps(c, 66)))
