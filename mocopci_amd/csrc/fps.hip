@@ -286,9 +286,9 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
     SpatialSort<T, P>().sort(keys, *reinterpret_cast<typename SpatialSort<T, P>::storage_type *>(sort_lds));
     // 4. a lane takes P consecutive points of the curve; box of the valid ones
     float px[P], py[P], pz[P], pt[P];
-    // low key word: 14-bit tie rank above the 14-bit original index.  n >= 1024 here, so the reference block is 1024
+    // low key word: 14-bit tie rank above the point's BYTE OFFSET in the coordinate array (index * 12 < 2^18).  n >= 1024 here, so the reference block is 1024
     // threads (L = 10) and sec(k) = bitrev10(k mod 1024) << 22 | k >> 10 compacts, order preserved, to
-    // bitrev10(k mod 1024) << 4 | k >> 10; the winner's index then needs no decoding.
+    // bitrev10(k mod 1024) << 4 | k >> 10; the winner's coordinates are then one mask away (no decode, no multiply).
     uint32_t tag[P];
     float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
     float best = -1.0f;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
         py[p] = xyz[src * 3 + 1];
         pz[p] = xyz[src * 3 + 2];
         pt[p] = ok ? temp[src] : -INFINITY;  // never selected, never stored
-        tag[p] = ((0x3FFFu - (((__brev((uint32_t)src & 1023u) >> 22) << 4) | ((uint32_t)src >> 10))) << 14) | (uint32_t)src;
+        tag[p] = ((0x3FFFu - (((__brev((uint32_t)src & 1023u) >> 22) << 4) | ((uint32_t)src >> 10))) << 18) | ((uint32_t)src * 12u);
         if (ok) {
             lox = fminf(lox, px[p]); loy = fminf(loy, py[p]); loz = fminf(loz, pz[p]);
             hix = fmaxf(hix, px[p]); hiy = fmaxf(hiy, py[p]); hiz = fmaxf(hiz, pz[p]);
@@ -332,10 +332,11 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
     for (int j = 1; j < m; ++j) {
         float x1, y1, z1;
         if (LDS_XYZ) {
-            const float *c = sxyz + __umul24(old, 3);  // 24-bit multiply: full rate, old < 2^14
+            const float *c = reinterpret_cast<const float *>(reinterpret_cast<const char *>(sxyz) + old);
             x1 = c[0]; y1 = c[1]; z1 = c[2];
         } else {
-            x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
+            const float *c = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xyz) + old);
+            x1 = c[0]; y1 = c[1]; z1 = c[2];
         }
         FPS_STAMP(0);  // centre read
         // exact lower bound of the lane's point distances (see the header comment); an all-padding lane has best = -1
@@ -379,20 +380,20 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
         const int s_new = 3 - s_cur - s_nxt;
         s_cur = s_nxt;
         s_nxt = s_new;
-        old = (int)(wlo & 0x3FFFu);
+        old = (int)(wlo & 0x3FFFFu);  // byte offset of the new centre
         if (tid == 0) {
-            if (lds_idx) sidx[j] = old;
-            else idxs[j] = old;
+            if (lds_idx) sidx[j] = old;  // offsets; converted to indices in the final flush
+            else idxs[j] = old / 12;
         }
         FPS_STAMP(4);  // slot read + store
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        if (tid * P + p < n) temp[tag[p] & 0x3FFFu] = pt[p];
+        if (tid * P + p < n) temp[(tag[p] & 0x3FFFFu) / 12u] = pt[p];
     }
     if (lds_idx) {
         __syncthreads();
-        for (int i = tid; i < m; i += T) idxs[i] = sidx[i];
+        for (int i = tid; i < m; i += T) idxs[i] = sidx[i] / 12;
     }
 }
 
