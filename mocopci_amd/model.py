@@ -211,12 +211,16 @@ class MoCoPCI(nn.Module):
             if key not in P:  # the layer's weights in the kernel's operand layout, built once
                 P[key] = be.cross_pack(self.W(pos), self.Bv(pos), self.W(conv), self.Bv(conv))
             return be.cross_volume(xyz1, xyz2, points1.contiguous(), points2.contiguous(), idx, P[key])
-        direction = be.group_rows(xyz2, idx) - xyz1.unsqueeze(2)          # (B,N1,32,3)
-        g2 = be.group_rows(points2, idx)                                  # (B,N1,32,D)
-        x = leaky((g2 + points1.unsqueeze(2)) + self.lin(direction, pos))
-        for name in mlp:
+        # Unfused path (D = 256 at level 3).  pos(xyz2[idx] - xyz1) is linear, so it is applied per POINT, not per
+        # (point, neighbour): a2 = points2 + W xyz2 is gathered, a1 = points1 - W xyz1 + b is broadcast.
+        wpos = self.W(pos)
+        a2 = points2 + F.linear(xyz2, wpos)
+        a1 = points1 - F.linear(xyz1, wpos, None if self.Bv(pos) is None else -self.Bv(pos))
+        x = leaky(be.group_rows(a2, idx) + a1.unsqueeze(2))               # (B,N1,32,D)
+        for name in mlp[:-1]:
             x = leaky(self.lin(x, name + ".composed_module.0"))
-        return x.max(dim=2)[0]
+        # LeakyReLU is monotone: the max over the 32 neighbours commutes with it
+        return leaky(self.lin(x, mlp[-1] + ".composed_module.0").max(dim=2)[0])
 
     def interp(self, dense, sparse, feat, cache=None, key=None):
         """UpsampleFlow (mocopci.py:1485-1502) with search reuse on a keyed (dense, sparse) pair."""
