@@ -26,16 +26,53 @@ constexpr int K = 16, QS = 16, CHK = 4, RT = 32, WAVES = 4;
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// x / sqrt(sum(x^2) + 1e-8): sequential sum of rounded squares (oracle canon), one thread per row
-__global__ __launch_bounds__(256) void normalize_rows_kernel(long long rows, int c, const float *__restrict__ x, float *__restrict__ y) {
-    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const float *xr = x + r * c;
-    float s = 0.f;
-    for (int j = 0; j < c; ++j) s = s + xr[j] * xr[j];
-    const float den = sqrtf(s + 1e-8f);
-    float *yr = y + r * c;
-    for (int j = 0; j < c; ++j) yr[j] = xr[j] / den;
+// x / sqrt(sum(x^2) + 1e-8): sequential sum of rounded squares (oracle canon).  A wave stages RW consecutive rows
+// through LDS with coalesced float4 traffic (rows are contiguous in memory), lane r < RW sums row r in channel order
+// from a padded (conflict-free) tile, and the scaled rows go back out coalesced.
+template <int C>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(long long rows, const float *__restrict__ x, float *__restrict__ y) {
+    constexpr int RW = C <= 64 ? 64 : (C == 128 ? 32 : 16), S = C + 1, V = RW * C / 4;  // float4s per tile
+    __shared__ float tile[4][RW * S];
+    __shared__ float den[4][RW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *t = tile[wave];
+    for (long long r0 = ((long long)blockIdx.x * 4 + wave) * RW; r0 < rows; r0 += (long long)gridDim.x * 4 * RW) {
+        const int live = (int)min((long long)RW, rows - r0);
+        const float4 *src = reinterpret_cast<const float4 *>(x + r0 * C);
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < V; e += 64) {
+            const int row = (e * 4) / C, col = (e * 4) % C;
+            if (row < live) {
+                const float4 v = src[e];
+                float *d = t + row * S + col;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < live) {
+            const float *xr = t + lane * S;
+            float s = 0.f;
+            for (int j = 0; j < C; ++j) s = s + xr[j] * xr[j];
+            den[wave][lane] = sqrtf(s + 1e-8f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4 *dst = reinterpret_cast<float4 *>(y + r0 * C);
+        for (int e = lane; e < V; e += 64) {
+            const int row = (e * 4) / C, col = (e * 4) % C;
+            if (row < live) {
+                const float *d = t + row * S + col;
+                const float dn = den[wave][row];
+                dst[e] = make_float4(d[0] / dn, d[1] / dn, d[2] / dn, d[3] / dn);
+            }
+        }
+    }
+}
+
+template <int C>
+void launch_normalize(long long rows, const float *x, float *y, hipStream_t s) {
+    constexpr int RW = C <= 64 ? 64 : (C == 128 ? 32 : 16);
+    const long long blocks = (rows + 4 * RW - 1) / (4 * RW);
+    hipLaunchKernelGGL(normalize_rows_kernel<C>, dim3((unsigned)min(blocks, 4096LL)), dim3(256), 0, s, rows, x, y);
 }
 
 template <int C>
@@ -148,12 +185,14 @@ MCP_EXPORT int mcp_knn_cosine(int b, int q, int n, int c, int k, const float *qf
                               float *workspace, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && q > 0 && n > 0 && c > 0 && k > 0 && qfeat && rfeat && idx && workspace);
     if (k > K || (c != 64 && c != 128 && c != 256)) return MCP_ERR_UNSUPPORTED;
+    if ((((uintptr_t)qfeat) | ((uintptr_t)rfeat) | ((uintptr_t)workspace)) & 15) return MCP_ERR_BAD_ARG;  // float4 row traffic
     hipStream_t s = (hipStream_t)stream;
     float *nq = workspace, *nr = workspace + (size_t)b * q * c;
     mcp_prof_begin(MCP_KERNEL_KNN_COSINE, s);
     const long long rq = (long long)b * q, rr = (long long)b * n;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((rq + 255) / 256)), dim3(256), 0, s, rq, c, qfeat, nq);
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, s, rr, c, rfeat, nr);
+    if (c == 64) { launch_normalize<64>(rq, qfeat, nq, s); launch_normalize<64>(rr, rfeat, nr, s); }
+    else if (c == 128) { launch_normalize<128>(rq, qfeat, nq, s); launch_normalize<128>(rr, rfeat, nr, s); }
+    else { launch_normalize<256>(rq, qfeat, nq, s); launch_normalize<256>(rr, rfeat, nr, s); }
     int rc = mcp_launch_status();
     if (rc == MCP_OK) {
         rc = c == 64    ? launch_cosine<64>(b, q, n, k, nq, nr, idx, dist, s)
