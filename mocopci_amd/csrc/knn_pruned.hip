@@ -383,6 +383,28 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
         }
     };
 
+    // Second, per-query filter.  Tiles are ordered (and the walk is ended) by their distance to the wave's QUERY BOX, which
+    // under-estimates badly when the 16 queries of a wave are spread out or far from the references.  A tile that passes
+    // the box test is scanned only if, for at least one query, the squared distance from the query POINT to the tile box
+    // is within that query's own threshold (same rounding slack as the box test).
+    auto wanted = [&](int tt) -> bool {
+        const float *bx = boxes + tt * 6;  // wave-uniform address
+        const float g0 = fmaxf(0.f, fmaxf(bx[0] - qx, qx - bx[3]));
+        const float g1 = fmaxf(0.f, fmaxf(bx[1] - qy, qy - bx[4]));
+        const float g2 = fmaxf(0.f, fmaxf(bx[2] - qz, qz - bx[5]));
+        const float g = g0 * g0 + g1 * g1 + g2 * g2;
+        return __builtin_amdgcn_ballot_w64(g <= tau + (tau * slack_rel + slack_abs)) != 0;  // dead lanes: tau = -inf
+    };
+    // next tile in bound order that passes both tests; -1 ends the walk (every later tile has a larger box bound)
+    auto next_wanted = [&]() -> int {
+        for (;;) {
+            float bd = 0.f;
+            const int tt = next_tile(bd);
+            if (tt < 0 || !(bd <= taumax + (taumax * slack_rel + slack_abs))) return -1;
+            if (wanted(tt)) return tt;
+        }
+    };
+
     float bound = 0.f;
     int t = next_tile(bound);  // the first tile is always visited (tau = +inf)
     TileRegs cur, nxt;
@@ -390,8 +412,7 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
     KNN_COUNT(0, 1);
     while (t >= 0) {
         KNN_COUNT(1, 1);
-        float bound2 = 0.f;
-        const int t2 = next_tile(bound2);
+        int t2 = next_wanted();  // chosen with the thresholds as they stand BEFORE this tile's scan ...
         if (t2 >= 0) fetch(t2, nxt);
         // stage the tile: coordinates + squared norm in reference order, original indices grouped per sub-lane
         __builtin_amdgcn_wave_barrier();
@@ -436,8 +457,12 @@ __global__ __launch_bounds__(64) void knn_pruned_kernel(int q, int n, int tiles,
         // tighten tau before the next pruning decision, but only when a queue is at least half full: a stale
         // (larger) tau is still a valid bound, it just prunes a little less
         if (__builtin_amdgcn_ballot_w64(cnt >= QS / 2)) flush();
-        // the next tile is visited only if its bound can still beat some lane's threshold
-        if (t2 < 0 || !(bound2 <= taumax + (taumax * slack_rel + slack_abs))) break;
+        // ... and re-examined with the tightened ones: the prefetched tile may have become useless (its loads are then
+        // wasted and the next candidate is fetched without overlap)
+        if (t2 >= 0 && !wanted(t2)) {
+            t2 = next_wanted();
+            if (t2 >= 0) fetch(t2, nxt);
+        }
         t = t2;
         cur = nxt;
     }
