@@ -127,6 +127,9 @@ int mcp_knn_cosine(int b, int q, int n, int c, int k, const float *qfeat, const 
 /* index_points_group / index_points_gather (mocopci.py:1190-1215) without the permute copies:
  * points (B,N,C) channel-last, idx (B,T) -> out (B,T,C) (T = S*K or S), whole C*4-byte rows. */
 int mcp_group_rows(int b, int n, int c, int t, const float *points, const int *idx, float *out, mcp_stream_t stream);
+/* its backward (channel-last counterpart of group_points_grad, group_points_gpu.cu:49-75): grad_out (B,T,C), idx (B,T)
+ * -> grad_points (B,N,C) += scatter; the caller zero-initialises grad_points. */
+int mcp_group_rows_grad(int b, int n, int c, int t, const float *grad_out, const int *idx, float *grad_points, mcp_stream_t stream);
 
 /* UpsampleFlow.forward (mocopci.py:1485-1502) / the interpolation half of PointWarping (:1472-1479):
  * dense (B,N,3), sparse (B,S,3), feat (B,S,C) channel-last -> out (B,N,C);
@@ -140,6 +143,10 @@ int mcp_interp3_weights(int b, int n, int s, const float *dense, const float *sp
                         mcp_stream_t stream);
 int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, const int *idx3, const float *w3, float *out,
                       mcp_stream_t stream);
+/* backward of mcp_interp3_apply w.r.t. feat (channel-last counterpart of three_interpolate_grad, interpolate_gpu.cu:126-150):
+ * grad_out (B,N,C) -> grad_feat (B,S,C) += w3 * grad_out at idx3; the caller zero-initialises grad_feat. */
+int mcp_interp3_apply_grad(int b, int n, int s, int c, const float *grad_out, const int *idx3, const float *w3, float *grad_feat,
+                           mcp_stream_t stream);
 
 /* MultiFrameEstimatier.knn_group + fusion (mocopci.py:798-819) after the two neighbour searches:
  * p1 (B,N,3) centres, p2 (B,N,3) gathered set, idx (B,N,64) int32 into p2 (32 self-neighbours of p1

@@ -63,7 +63,34 @@ __global__ __launch_bounds__(BLK) void interp3_apply_kernel(int n, int s, int cv
         out[g] = o;
     }
 }
+// Backward of the blend w.r.t. the sparse features: grad_feat[b, idx3[b,p,j], :] += w3[b,p,j] * grad_out[b,p,:]
+// (channel-last counterpart of K9, three_interpolate_grad_kernel, interpolate_gpu.cu:126-150)
+__global__ __launch_bounds__(BLK) void interp3_apply_grad_kernel(int n, int s, int c, long long total, const float *__restrict__ grad_out,
+                                                                 const int *__restrict__ idx3, const float *__restrict__ w3,
+                                                                 float *__restrict__ grad_feat) {
+    long long g = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long stride = (long long)gridDim.x * BLK;
+    for (; g < total; g += stride) {
+        const long long row = g / c;  // b*n + p
+        const int col = (int)(g - row * c);
+        const int b = (int)(row / n);
+        const float go = grad_out[g];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            atomicAdd(grad_feat + ((long long)b * s + idx3[row * 3 + j]) * c + col, w3[row * 3 + j] * go);
+    }
+}
 }  // namespace
+
+MCP_EXPORT int mcp_interp3_apply_grad(int b, int n, int s, int c, const float *grad_out, const int *idx3, const float *w3,
+                                      float *grad_feat, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && s > 0 && c > 0 && grad_out && idx3 && w3 && grad_feat);
+    const long long total = (long long)b * n * c;
+    const unsigned grid = (unsigned)min((total + BLK - 1) / BLK, 8192LL);
+    hipLaunchKernelGGL(interp3_apply_grad_kernel, dim3(grid), dim3(BLK), 0, (hipStream_t)stream, n, s, c, total, grad_out, idx3, w3,
+                       grad_feat);
+    return mcp_launch_status();
+}
 
 MCP_EXPORT int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, const int *idx3, const float *w3, float *out,
                                  mcp_stream_t stream) {

@@ -80,6 +80,20 @@ __global__ __launch_bounds__(BLK) void group_rows_kernel(int n, int cv, long lon
     }
 }
 
+// Backward of the row gather: grad_points[b, idx[b,t], :] += grad_out[b,t,:]  (the channel-last counterpart of K6,
+// group_points_grad_kernel, group_points_gpu.cu:49-75: same atomicAdd scatter, whole rows instead of strided scalars)
+__global__ __launch_bounds__(BLK) void group_rows_grad_kernel(int n, int c, long long total, int t, const float *__restrict__ grad_out,
+                                                              const int *__restrict__ idx, float *__restrict__ grad_points) {
+    long long g = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long stride = (long long)gridDim.x * BLK;
+    for (; g < total; g += stride) {
+        const long long row = g / c;
+        const int col = (int)(g - row * c);
+        const int b = (int)(row / t);
+        atomicAdd(grad_points + ((long long)b * n + idx[row]) * c + col, grad_out[g]);
+    }
+}
+
 // K4  ball_query_gpu.cu:9-45.  The reference gives one thread per centre a serial scan of all N points with an
 // early break.  Here a WAVE owns a centre: lane l tests points 64*i + l (coalesced reads), the hit mask of each step
 // is a ballot, and a hit's output slot is (hits so far) + (hits in lower lanes) -- exactly the reference's index
@@ -253,6 +267,15 @@ MCP_EXPORT int mcp_group_rows(int b, int n, int c, int t, const float *points, c
         hipLaunchKernelGGL((group_rows_kernel<float, 1>), dim3(grid), dim3(BLK), 0, s, n, c, total, t, points, idx, out);
     }
     mcp_prof_end(MCP_KERNEL_GROUP_ROWS, s);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_group_rows_grad(int b, int n, int c, int t, const float *grad_out, const int *idx, float *grad_points,
+                                   mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && c > 0 && t > 0 && grad_out && idx && grad_points);
+    const long long total = (long long)b * t * c;
+    const unsigned grid = (unsigned)min((long long)mcp_divup((unsigned)min(total, (long long)0x7fffffff), BLK), 8192LL);
+    hipLaunchKernelGGL(group_rows_grad_kernel, dim3(grid), dim3(BLK), 0, (hipStream_t)stream, n, c, total, t, grad_out, idx, grad_points);
     return mcp_launch_status();
 }
 

@@ -29,6 +29,64 @@ def _call(name, ref_tensor, *args):
         _lib.check(getattr(lib, name)(*args, _lib.stream()))
 
 
+def _group_rows_fwd(points, idx):
+    B, N, C = points.shape
+    idx = idx.contiguous()
+    T = idx[0].numel()
+    out = torch.empty((*idx.shape, C), dtype=torch.float32, device=points.device)
+    _call("mcp_group_rows", points, B, N, C, T, _lib.fptr(points), _lib.iptr(idx), _lib.fptr(out))
+    return out
+
+
+def _interp3_apply_fwd(feat, idx3, w3):
+    B, N, _ = idx3.shape
+    S, C = feat.shape[1], feat.shape[2]
+    out = torch.empty((B, N, C), dtype=torch.float32, device=feat.device)
+    _call("mcp_interp3_apply", feat, B, N, S, C, _lib.fptr(feat), _lib.iptr(idx3), _lib.fptr(w3), _lib.fptr(out))
+    return out
+
+
+class _GroupRowsFn(torch.autograd.Function):
+    """Row gather with its scatter-add backward (channel-last counterpart of GroupingOperation, pointnet2_utils.py:156-198)."""
+
+    @staticmethod
+    def forward(ctx, points, idx):
+        idx = idx.contiguous()
+        ctx.save_for_backward(idx)
+        ctx.n = points.shape[1]
+        return _group_rows_fwd(points.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        B, C = grad_out.shape[0], grad_out.shape[-1]
+        T = idx[0].numel()
+        grad_out = grad_out.contiguous()
+        grad = torch.zeros((B, ctx.n, C), dtype=torch.float32, device=grad_out.device)
+        _call("mcp_group_rows_grad", grad_out, B, ctx.n, C, T, _lib.fptr(grad_out), _lib.iptr(idx), _lib.fptr(grad))
+        return grad, None
+
+
+class _Interp3ApplyFn(torch.autograd.Function):
+    """Three-neighbour blend with its backward w.r.t. the sparse features (counterpart of ThreeInterpolate, pointnet2_utils.py:108-153)."""
+
+    @staticmethod
+    def forward(ctx, feat, idx3, w3):
+        idx3, w3 = idx3.contiguous(), w3.contiguous()
+        ctx.save_for_backward(idx3, w3)
+        ctx.s = feat.shape[1]
+        return _interp3_apply_fwd(feat.contiguous(), idx3, w3)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx3, w3 = ctx.saved_tensors
+        B, N, C = grad_out.shape
+        grad_out = grad_out.contiguous()
+        grad = torch.zeros((B, ctx.s, C), dtype=torch.float32, device=grad_out.device)
+        _call("mcp_interp3_apply_grad", grad_out, B, N, ctx.s, C, _lib.fptr(grad_out), _lib.iptr(idx3), _lib.fptr(w3), _lib.fptr(grad))
+        return grad, None, None
+
+
 class HipBackend:
     name = "hip"
 
@@ -121,13 +179,10 @@ class HipBackend:
 
     def group_rows(self, points, idx):
         """index_points_group / index_points_gather (mocopci.py:1190-1215): points (B,N,C),
-        idx (B,...) int32 -> (B,...,C)."""
-        B, N, C = points.shape
-        idx = idx.contiguous()
-        T = idx[0].numel()
-        out = torch.empty((*idx.shape, C), dtype=torch.float32, device=points.device)
-        _call("mcp_group_rows", points, B, N, C, T, _lib.fptr(points), _lib.iptr(idx), _lib.fptr(out))
-        return out
+        idx (B,...) int32 -> (B,...,C).  Differentiable w.r.t. points (scatter-add backward kernel)."""
+        if points.requires_grad and torch.is_grad_enabled():
+            return _GroupRowsFn.apply(points, idx)
+        return _group_rows_fwd(points, idx)
 
     def interp3_search(self, dense, sparse):
         """3-NN search + inverse-distance weights of UpsampleFlow (mocopci.py:1494-1498)."""
@@ -139,11 +194,10 @@ class HipBackend:
         return idx3, w3
 
     def interp3_apply(self, feat, idx3, w3):
-        B, N, _ = idx3.shape
-        S, C = feat.shape[1], feat.shape[2]
-        out = torch.empty((B, N, C), dtype=torch.float32, device=feat.device)
-        _call("mcp_interp3_apply", feat, B, N, S, C, _lib.fptr(feat), _lib.iptr(idx3), _lib.fptr(w3), _lib.fptr(out))
-        return out
+        """Blend of the three neighbours' rows; differentiable w.r.t. feat (scatter-add backward kernel)."""
+        if feat.requires_grad and torch.is_grad_enabled():
+            return _Interp3ApplyFn.apply(feat, idx3, w3)
+        return _interp3_apply_fwd(feat, idx3, w3)
 
     def interp3(self, dense, sparse, feat):
         """UpsampleFlow.forward (mocopci.py:1485-1502): dense (B,N,3), sparse (B,S,3), feat (B,S,C) -> (B,N,C)."""

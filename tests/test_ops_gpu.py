@@ -174,6 +174,53 @@ def test_interp3_bit_exact(n, s, c):
     assert torch.equal(be.interp3_apply(feat.to(DEV), idx3, w3).cpu(), want)
 
 
+def test_channel_last_backward_kernels_match_autograd():
+    # group_rows / interp3_apply backward (atomic scatter-adds: summation order differs, hence the tolerance) against
+    # torch autograd through plain indexing of the same forward
+    be = ops.backend()
+    g = torch.Generator().manual_seed(12)
+    pts = torch.randn(2, 300, 20, generator=g).to(DEV).requires_grad_(True)
+    idx = torch.randint(0, 300, (2, 70, 9), generator=g, dtype=torch.int32).to(DEV)
+    go = torch.randn(2, 70, 9, 20, generator=g).to(DEV)
+    out = be.group_rows(pts, idx)
+    out.backward(go)
+    ref = pts.detach().clone().requires_grad_(True)
+    torch.stack([ref[b][idx[b].long()] for b in range(2)]).backward(go)
+    assert torch.equal(out.detach(), torch.stack([ref[b][idx[b].long()] for b in range(2)]).detach())
+    torch.testing.assert_close(pts.grad, ref.grad, rtol=1e-5, atol=1e-5)
+    dense, sparse = cloud(61, 2, 500).to(DEV), cloud(62, 2, 120).to(DEV)
+    feat = torch.randn(2, 120, 12, generator=g).to(DEV).requires_grad_(True)
+    i3, w3 = be.interp3_search(dense, sparse)
+    go = torch.randn(2, 500, 12, generator=g).to(DEV)
+    be.interp3_apply(feat, i3, w3).backward(go)
+    ref = feat.detach().clone().requires_grad_(True)
+    blend = torch.stack([(ref[b][i3[b].long()] * w3[b].unsqueeze(-1)).sum(dim=1) for b in range(2)])
+    blend.backward(go)
+    torch.testing.assert_close(feat.grad, ref.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_edge_shapes_and_error_codes():
+    be = ops.backend()
+    x = cloud(71, 1, 10).to(DEV)
+    # fewer references than K: the list is padded by repeating its last valid entry (documented in mcp_knn)
+    i, d = be.knn(x, x[:, :5].contiguous(), 16, return_dist=True)
+    wi, wd = orc.knn(x.cpu(), x[:, :5].cpu().contiguous(), 16, return_dist=True)
+    assert torch.equal(i.cpu(), wi) and torch.equal(d.cpu(), wd)
+    # a single query / a single reference
+    assert torch.equal(be.knn(x[:, :1].contiguous(), x, 3).cpu(), orc.knn(x[:, :1].cpu().contiguous(), x.cpu(), 3))
+    assert int(be.knn(x, x[:, :1].contiguous(), 1).abs().sum()) == 0
+    # npoint == 1 and npoint == n
+    assert pu.furthest_point_sample(x, 1).tolist() == [[0]]
+    assert sorted(pu.furthest_point_sample(x, 10)[0].tolist()) == list(range(10))
+    # unsupported shapes fail loudly, never fall back
+    with pytest.raises(RuntimeError):
+        be.knn(x, x, 40)
+    with pytest.raises(RuntimeError):
+        be.knn_cosine(torch.randn(1, 8, 48, device=DEV), torch.randn(1, 8, 48, device=DEV), 4)
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        be.knn(x.cpu(), x.cpu(), 3)
+
+
 def test_chamfer_matches_oracle():
     x, y = cloud(61, 2, 4096), cloud(62, 2, 3000)
     got = float(ops.backend().chamfer(x.to(DEV), y.to(DEV)))
