@@ -115,20 +115,32 @@ class MoCoPCI(nn.Module):
         return torch.addcmul(shift, x, scale)
 
     # ---- point-set layers ---------------------------------------------------------------
-    def pointconv(self, prefix, s_xyz, new_xyz, s_points, nsample=32):
+    def pointconv(self, prefix, s_xyz, new_xyz, s_points, nsample=32, idx=None):
         """PointConv / PointConvD body after sampling (mocopci.py:1315-1346, :1362-1396; group /
-        group_query :1218-1266; WeightNet :1289-1300)."""
+        group_query :1218-1266; WeightNet :1289-1300).  idx: the (B,S,nsample) neighbour lists when the caller
+        already has them (see sampled_neighbours)."""
         be = ops.backend()
         B, S, _ = new_xyz.shape
-        idx = be.knn(new_xyz, s_xyz, nsample)
+        if idx is None:
+            idx = be.knn(new_xyz, s_xyz, nsample)
         wn = [t for i in range(3) for t in (self.W(f"{prefix}.weightnet.mlp_convs.{i}"), self.Bv(f"{prefix}.weightnet.mlp_convs.{i}"))]
         agg = be.pointconv_agg(s_xyz, new_xyz, s_points.contiguous(), idx, *wn)      # (B,S,(3+D)*8)
         return leaky(self.lin(agg, prefix + ".linear"))
 
-    def fps_gather(self, xyz, npoint):
+    def fps_gather(self, xyz, npoint, return_idx=False):
         """furthest_point_sample + index_points_gather (mocopci.py:1378-1379)."""
         be = ops.backend()
-        return be.group_rows(xyz, be.fps(xyz, npoint))
+        sel = be.fps(xyz, npoint)
+        pts = be.group_rows(xyz, sel)
+        return (pts, sel) if return_idx else pts
+
+    @staticmethod
+    def sampled_neighbours(idx_self, sel):
+        """Neighbour lists of FPS-sampled points among the cloud they were sampled from.  A sampled point IS a point of that
+        cloud (bit-identical coordinates), so its K nearest in the cloud are the row of the cloud's self-search at its index:
+        knn(cloud[sel], cloud, K) == knn(cloud, cloud, K)[sel], same distance form, same (distance, index) order.  The rows
+        are moved as raw 32-bit words."""
+        return ops.backend().group_rows(idx_self.view(torch.float32), sel).view(torch.int32)
 
     def side_stream(self, device):
         """Second HIP stream for the serial FPS chains (one workgroup per batch element, latency-bound): they
@@ -153,15 +165,18 @@ class MoCoPCI(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 pcs = [xyz]
+                sel1 = None
                 for lvl, npoint in enumerate((2048, 512, 256, 64), start=1):
-                    pcs.append(self.fps_gather(pcs[-1], npoint))
+                    pts, sel = self.fps_gather(pcs[-1], npoint, return_idx=True)
+                    pcs.append(pts)
+                    sel1 = sel if lvl == 1 else sel1
                     ready[lvl] = torch.cuda.Event()
                     ready[lvl].record(side)
             _, pc1, pc2, pc3, pc4 = pcs
-            for t in (pc1, pc2, pc3, pc4):  # allocated on the side stream, consumed on the main stream
+            for t in (pc1, pc2, pc3, pc4, sel1):  # allocated on the side stream, consumed on the main stream
                 t.record_stream(main)
         else:
-            pc1 = self.fps_gather(xyz, 2048)
+            pc1, sel1 = self.fps_gather(xyz, 2048, return_idx=True)
             pc2 = self.fps_gather(pc1, 512)
             pc3 = self.fps_gather(pc2, 256)
             pc4 = self.fps_gather(pc3, 64)
@@ -171,10 +186,12 @@ class MoCoPCI(nn.Module):
                 main.wait_event(ready[lvl])
 
         f0 = self.conv1d_block(xyz, p + "level0_lift")
-        f0 = self.pointconv(p + "level0", xyz, xyz, f0)
+        idx0 = ops.backend().knn(xyz, xyz, 32)
+        f0 = self.pointconv(p + "level0", xyz, xyz, f0, idx=idx0)
         f0_1 = self.conv1d_block(f0, p + "level0_1")
         need(1)
-        f1 = self.pointconv(p + "level1", xyz, pc1, f0_1)
+        # level 1 searches the 32 nearest of pc1 = xyz[sel1] in xyz: rows of the level-0 self search
+        f1 = self.pointconv(p + "level1", xyz, pc1, f0_1, idx=self.sampled_neighbours(idx0, sel1))
         f1 = self.conv1d_block(f1, p + "level1_0")
         f1_2 = self.conv1d_block(f1, p + "level1_1")
         need(2)
@@ -516,17 +533,19 @@ class MoCoPCI(nn.Module):
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                down = self.fps_gather(warped, 2048)
+                down, sel = self.fps_gather(warped, 2048, return_idx=True)
                 done = torch.cuda.Event()
                 done.record(side)
             down.record_stream(main)
+            sel.record_stream(main)
         else:
-            down = self.fps_gather(warped, 2048)
+            down, sel = self.fps_gather(warped, 2048, return_idx=True)
         wf = self.conv1d_block(wf, m + "rlevel0")
         idx_self = ops.backend().knn(warped, warped, 32)      # fusion's self search: independent of the refine branch
         if side is not None:
             main.wait_event(done)
-        dfeat = self.pointconv(m + "level1", warped, down, wf)
+        # down = warped[sel]: its 32 nearest in warped are rows of the self search the fusion stage needs anyway
+        dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel))
         shape = self.transformer_block(m + "shape1", dfeat, down)
         upf = ops.backend().interp3(warped, down, shape)
         refine = self.lin(F.relu(self.lin(upf, m + "pred.0")), m + "pred.2")       # (3B,N,3)

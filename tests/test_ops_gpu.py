@@ -335,6 +335,18 @@ def test_interp3_search_pruned_route_matches_oracle():
     torch.testing.assert_close(got, orc.interp3(dense, sparse, feat), rtol=1e-6, atol=1e-7)
 
 
+def test_sampled_neighbours_are_rows_of_the_self_search():
+    # model.sampled_neighbours: the K nearest of an FPS-sampled point in its own cloud = the self search's row (dup points included)
+    from mocopci_amd.model import MoCoPCI
+    be = ops.backend()
+    x = cloud(301, 2, 8192).to(DEV)
+    sel = pu.furthest_point_sample(x, 2048)
+    sub = be.group_rows(x, sel)
+    direct = be.knn(sub, x, 32)
+    assert torch.equal(MoCoPCI.sampled_neighbours(be.knn(x, x, 32), sel), direct)
+    assert torch.equal(direct.cpu(), orc.knn(sub.cpu(), x.cpu(), 32))
+
+
 def test_knn_pruned_clustered_and_degenerate_clouds():
     be = ops.backend()
     g = torch.Generator().manual_seed(5)
