@@ -46,9 +46,10 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_kernel(int nq, int
     for (int s = 0; s < HD / 2; ++s) qf[s] = q[2 * s + h] * scale_log2e;
 
     float m = -INFINITY, l = 0.f;
-    float o[HD];
+    // output accumulators as float pairs: P.V runs on v_pk_fma_f32 (two fma per lane and instruction)
+    f2 o[HD / 2];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    for (int d = 0; d < HD / 2; ++d) o[d] = f2{0.f, 0.f};
 
     // stage loader: thread t loads one float4 of K or V
     constexpr int F4_PER_TILE = KT * HD / 4;                 // float4s per K (or V) stage
@@ -116,20 +117,20 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_kernel(int nq, int
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
             m = mn;
             l *= alpha;
+            const f2 alpha2 = {alpha, alpha};
 #pragma unroll
-            for (int d = 0; d < HD; ++d) o[d] *= alpha;
+            for (int d = 0; d < HD / 2; ++d) o[d] *= alpha2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(acc[r] - mn);
                 l += p;
                 const float *vr = &vt[cur][(sub * 32 + chan_of(r, h)) * HD];
+                const f2 p2 = {p, p};
 #pragma unroll
                 for (int d = 0; d < HD; d += 4) {
                     const float4 vv = *reinterpret_cast<const float4 *>(vr + d);
-                    o[d + 0] = __builtin_fmaf(p, vv.x, o[d + 0]);
-                    o[d + 1] = __builtin_fmaf(p, vv.y, o[d + 1]);
-                    o[d + 2] = __builtin_fmaf(p, vv.z, o[d + 2]);
-                    o[d + 3] = __builtin_fmaf(p, vv.w, o[d + 3]);
+                    o[d / 2 + 0] = __builtin_elementwise_fma(p2, f2{vv.x, vv.y}, o[d / 2 + 0]);
+                    o[d / 2 + 1] = __builtin_elementwise_fma(p2, f2{vv.z, vv.w}, o[d / 2 + 1]);
                 }
             }
         }
@@ -143,7 +144,10 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_kernel(int nq, int
     const float inv = 1.0f / lsum;
     float res[HD];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) res[d] = (o[d] * a0 + __shfl_xor(o[d], 32) * a1) * inv;
+    for (int d = 0; d < HD; ++d) {
+        const float od = (d & 1) ? o[d / 2].y : o[d / 2].x;
+        res[d] = (od * a0 + __shfl_xor(od, 32) * a1) * inv;
+    }
     if (live && h == 0) {
         float *dst = out + ((size_t)bf * nq + qi) * os + head * HD;
 #pragma unroll
