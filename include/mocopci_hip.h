@@ -127,6 +127,11 @@ int mcp_knn_cosine(int b, int q, int n, int c, int k, const float *qfeat, const 
 /* index_points_group / index_points_gather (mocopci.py:1190-1215) without the permute copies:
  * points (B,N,C) channel-last, idx (B,T) -> out (B,T,C) (T = S*K or S), whole C*4-byte rows. */
 int mcp_group_rows(int b, int n, int c, int t, const float *points, const int *idx, float *out, mcp_stream_t stream);
+/* grouping + centre offset + LeakyReLU, the first layer of cross() when it is not fused into mcp_cross_volume
+ * (pointconv_util.py:762-770): points (B,N,C), idx (B,S,K), centre (B,S,C) -> out (B,S,K,C) = leaky(points[idx] + centre).
+ * C % 4 == 0, 16-byte aligned pointers. */
+int mcp_group_rows_add_leaky(int b, int n, int c, int s, int k, float slope, const float *points, const int *idx,
+                             const float *centre, float *out, mcp_stream_t stream);
 /* its backward (channel-last counterpart of group_points_grad, group_points_gpu.cu:49-75): grad_out (B,T,C), idx (B,T)
  * -> grad_points (B,N,C) += scatter; the caller zero-initialises grad_points. */
 int mcp_group_rows_grad(int b, int n, int c, int t, const float *grad_out, const int *idx, float *grad_points, mcp_stream_t stream);

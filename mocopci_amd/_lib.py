@@ -40,6 +40,7 @@ SIGNATURES = {
     "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_interp3_apply_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_group_rows_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
+    "mcp_group_rows_add_leaky": [_i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     "mcp_fusion": [_i, _i, _i] + [_p] * 11,
     "mcp_cross_packed_floats": [_i],
     "mcp_cross_pack": [_i, _p, _p, _p, _p, _p, _p],

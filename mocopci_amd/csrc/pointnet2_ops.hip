@@ -80,6 +80,25 @@ __global__ __launch_bounds__(BLK) void group_rows_kernel(int n, int cv, long lon
     }
 }
 
+// First layer of the cost-volume cross() in its unfused form (pointconv_util.py:762-770): gather the K neighbour rows of
+// every centre, add the centre's own row, LeakyReLU:  out[b,s,k,:] = leaky(points[b, idx[b,s,k], :] + centre[b,s,:]).
+__global__ __launch_bounds__(BLK) void group_rows_add_leaky_kernel(int n, int cv, long long total, int sk, int k, float slope,
+                                                                   const float4 *__restrict__ points, const int *__restrict__ idx,
+                                                                   const float4 *__restrict__ centre, float4 *__restrict__ out) {
+    long long g = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long stride = (long long)gridDim.x * BLK;
+    for (; g < total; g += stride) {
+        const long long row = g / cv;  // b*S*K + s*K + j
+        const int col = (int)(g - row * cv);
+        const int b = (int)(row / sk);
+        const float4 p = points[((long long)b * n + idx[row]) * cv + col], c = centre[(row / k) * cv + col];
+        float4 o = make_float4(p.x + c.x, p.y + c.y, p.z + c.z, p.w + c.w);
+        o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+        o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+        out[g] = o;
+    }
+}
+
 // Backward of the row gather: grad_points[b, idx[b,t], :] += grad_out[b,t,:]  (the channel-last counterpart of K6,
 // group_points_grad_kernel, group_points_gpu.cu:49-75: same atomicAdd scatter, whole rows instead of strided scalars)
 __global__ __launch_bounds__(BLK) void group_rows_grad_kernel(int n, int c, long long total, int t, const float *__restrict__ grad_out,
@@ -267,6 +286,19 @@ MCP_EXPORT int mcp_group_rows(int b, int n, int c, int t, const float *points, c
         hipLaunchKernelGGL((group_rows_kernel<float, 1>), dim3(grid), dim3(BLK), 0, s, n, c, total, t, points, idx, out);
     }
     mcp_prof_end(MCP_KERNEL_GROUP_ROWS, s);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_group_rows_add_leaky(int b, int n, int c, int s, int k, float slope, const float *points, const int *idx,
+                                        const float *centre, float *out, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && c > 0 && s > 0 && k > 0 && points && idx && centre && out);
+    if (c % 4 != 0 || ((((uintptr_t)points) | ((uintptr_t)centre) | ((uintptr_t)out)) & 15)) return MCP_ERR_BAD_ARG;
+    const int cv = c / 4;
+    const long long total = (long long)b * s * k * cv;
+    const unsigned grid = (unsigned)min((total + BLK - 1) / BLK, 16384LL);
+    hipLaunchKernelGGL(group_rows_add_leaky_kernel, dim3(grid), dim3(BLK), 0, (hipStream_t)stream, n, cv, total, s * k, k, slope,
+                       reinterpret_cast<const float4 *>(points), idx, reinterpret_cast<const float4 *>(centre),
+                       reinterpret_cast<float4 *>(out));
     return mcp_launch_status();
 }
 

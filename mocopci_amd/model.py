@@ -233,7 +233,7 @@ class MoCoPCI(nn.Module):
         wpos = self.W(pos)
         a2 = points2 + F.linear(xyz2, wpos)
         a1 = points1 - F.linear(xyz1, wpos, None if self.Bv(pos) is None else -self.Bv(pos))
-        x = leaky(be.group_rows(a2, idx) + a1.unsqueeze(2))               # (B,N1,32,D)
+        x = be.group_rows_add_leaky(a2.contiguous(), idx, a1.contiguous(), 0.1)   # leaky(a2[idx] + a1): (B,N1,32,D)
         for name in mlp[:-1]:
             x = leaky(self.lin(x, name + ".composed_module.0"))
         # LeakyReLU is monotone: the max over the 32 neighbours commutes with it

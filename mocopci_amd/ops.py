@@ -184,6 +184,16 @@ class HipBackend:
             return _GroupRowsFn.apply(points, idx)
         return _group_rows_fwd(points, idx)
 
+    def group_rows_add_leaky(self, points, idx, centre, slope=0.1):
+        """leaky(points[idx] + centre[:, :, None, :]): points (B,N,C), idx (B,S,K), centre (B,S,C) -> (B,S,K,C)
+        (first layer of the unfused cross(), pointconv_util.py:762-770)."""
+        B, N, C = points.shape
+        _, S, K = idx.shape
+        out = torch.empty((B, S, K, C), dtype=torch.float32, device=points.device)
+        _call("mcp_group_rows_add_leaky", points, B, N, C, S, K, ctypes.c_float(slope), _lib.fptr(points), _lib.iptr(idx.contiguous()),
+              _lib.fptr(centre), _lib.fptr(out))
+        return out
+
     def interp3_search(self, dense, sparse):
         """3-NN search + inverse-distance weights of UpsampleFlow (mocopci.py:1494-1498)."""
         B, N, _ = dense.shape

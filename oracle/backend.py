@@ -22,6 +22,9 @@ class OracleBackend:
     def group_rows(self, points, idx):
         return orc.group_rows(points, idx.int())
 
+    def group_rows_add_leaky(self, points, idx, centre, slope=0.1):
+        return torch.nn.functional.leaky_relu(orc.group_rows(points, idx.int()) + centre.unsqueeze(2), slope)
+
     def interp3_search(self, dense, sparse):
         idx3 = orc.knn(dense, sparse, 3, mode=0)
         B, N, _ = dense.shape

@@ -162,6 +162,15 @@ def test_group_rows(c):
     assert torch.equal(got, orc.group_rows(pts, idx))
 
 
+def test_group_rows_add_leaky_is_exact():
+    g = torch.Generator().manual_seed(8)
+    pts, ctr = torch.randn(2, 300, 24, generator=g), torch.randn(2, 70, 24, generator=g)
+    idx = torch.randint(0, 300, (2, 70, 9), generator=g, dtype=torch.int32)
+    want = torch.nn.functional.leaky_relu(orc.group_rows(pts, idx) + ctr.unsqueeze(2), 0.1)
+    got = ops.backend().group_rows_add_leaky(pts.to(DEV), idx.to(DEV), ctr.to(DEV), 0.1).cpu()
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("n,s,c", [(8192, 2048, 3), (2048, 512, 128), (512, 256, 256), (256, 64, 5)])
 def test_interp3_bit_exact(n, s, c):
     dense, sparse = cloud(51, 2, n), cloud(52, 2, s)
