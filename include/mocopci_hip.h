@@ -43,7 +43,9 @@ const char *mcp_error_string(int code);
 /* furthest_point_sampling_wrapper(b,n,m,points,temp,idx)   pointnet2/src/sampling.cpp:38-49,
  * kernel sampling_gpu.cu:93-253.  xyz (B,N,3); temp (B,N) scratch pre-filled with 1e10 by the
  * caller (pointnet2_utils.py:26), holds the final min-distances on return; idx (B,M) int32.
- * Bit-exact with the reference kernel's index sequence including its tie rule. */
+ * Bit-exact with the reference kernel's index sequence including its tie rule.
+ * 16384 < N <= 65536 takes B*ceil(N/64)*64*20 bytes of scratch from the stream-ordered allocator (hipMallocAsync /
+ * hipFreeAsync on `stream`) for the duration of the call; every other size uses no memory beyond the arguments. */
 int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx, mcp_stream_t stream);
 
 /* gather_points_wrapper(b,c,n,npoints,points,idx,out)      sampling.cpp:11-22, sampling_gpu.cu:8-44

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include <rocprim/block/block_radix_sort.hpp>
+#include <rocprim/block/block_scan.hpp>
 
 #include "common.h"
 
@@ -437,6 +438,260 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int L, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiled variant for 16384 < N <= 65536 (BASELINE config 5).  The points no longer fit in one workgroup's registers, so
+// they stay in memory -- but in a Morton-cell order built once by an in-LDS counting sort (2^15 cells, key bits shared out to the axes by extent), as
+// tiles of 64 consecutive points.  Every thread owns one tile: its bounding box, its largest running distance and that
+// point's key live in the thread's registers, the candidate's coordinates in LDS.  Per iteration a lane runs the same
+// exact box test as fps_spatial_kernel; only the tiles that can change are streamed (one coalesced 1 KB read + 256 B
+// write each, from L2), everything else is register work.  The plain streaming kernel below re-reads all N points per
+// iteration (30 ms at 8 x 65536 -> 2048; this one: a few ms).  Same (ord(d), ~sec(k)) total order, so the same indices.
+// Workspace (sorted float4 points + running distances) is taken from the stream-ordered allocator for the call.
+// ---------------------------------------------------------------------------------------------
+constexpr int TL_T = 1024, TL_PTS = 64, TL_CELLS = 32768, TL_BATCH = 4;
+using TiledScan = rocprim::block_scan<uint32_t, TL_T>;
+
+__device__ __forceinline__ uint32_t tl_spread5(uint32_t v) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) r |= ((v >> b) & 1u) << (3 * b);
+    return r;
+}
+// tie rank of original index k for a 1024-thread reference block: bitrev10(k mod 1024) << 6 | k >> 10  (k < 65536)
+__device__ __forceinline__ uint32_t tl_rank(uint32_t k) { return ((__brev(k & 1023u) >> 22) << 6) | (k >> 10); }
+__device__ __forceinline__ uint32_t tl_unrank(uint32_t r) { return (__brev(r >> 6) >> 22) | ((r & 63u) << 10); }
+
+__global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles, int lds_idx, const float *__restrict__ xyz,
+                                                         float *__restrict__ temp, int *__restrict__ idxs, float4 *__restrict__ sx,
+                                                         float *__restrict__ st) {
+    extern __shared__ float4 smem_f4[];
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_f4);                  // [3]
+    float(*red)[16] = reinterpret_cast<float(*)[16]>(reinterpret_cast<float *>(smem_f4) + 16);   // [6][16]
+    float *bbox = reinterpret_cast<float *>(smem_f4) + 112;                                       // [6]
+    char *body = reinterpret_cast<char *>(smem_f4) + 512;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(body);                                          // [TL_CELLS] during the sort
+    typename TiledScan::storage_type &scan_lds = *reinterpret_cast<typename TiledScan::storage_type *>(body + TL_CELLS * 4);
+    float4 *tcand = reinterpret_cast<float4 *>(body);                                             // [tiles] afterwards
+    int *sidx = reinterpret_cast<int *>(reinterpret_cast<char *>(smem_f4) + lds_idx);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = tiles * TL_PTS;
+    xyz += (size_t)blockIdx.x * n * 3;
+    temp += (size_t)blockIdx.x * n;
+    idxs += (size_t)blockIdx.x * m;
+    sx += (size_t)blockIdx.x * np;
+    st += (size_t)blockIdx.x * np;
+
+    // 1. bounding box, cleared histogram
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = tid; i < n; i += TL_T) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = xyz[(size_t)i * 3 + a];
+                lo[a] = fminf(lo[a], v);
+                hi[a] = fmaxf(hi[a], v);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float l = -mcp_unord(mcp_wave_max_u32(mcp_ord(-lo[a]))), h = mcp_unord(mcp_wave_max_u32(mcp_ord(hi[a])));
+            if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+        }
+        for (int c = tid; c < TL_CELLS; c += TL_T) hist[c] = 0u;
+        if (tid < 3) slots[tid] = 0ull;
+        __syncthreads();
+        if (tid < 6) {
+            float v = red[tid][0];
+            for (int w = 1; w < TL_T / 64; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+            bbox[tid] = v;
+        }
+        __syncthreads();
+    }
+    // 15 key bits shared out to the axes so that the cells come out as cubic as the extents allow (a LiDAR sweep is
+    // 160 x 160 x 10 m: x and y get 6 bits, z 3); bit s of the key (from the top) belongs to axis axis_of[s]
+    const float b0 = bbox[0], b1 = bbox[1], b2 = bbox[2];
+    float size[3] = {bbox[3] - b0, bbox[4] - b1, bbox[5] - b2};
+    int bits[3] = {0, 0, 0};
+    uint32_t axis_of = 0;  // 2 bits per key bit, top key bit first
+#pragma unroll
+    for (int sbit = 0; sbit < 15; ++sbit) {
+        const int a = size[0] >= size[1] ? (size[0] >= size[2] ? 0 : 2) : (size[1] >= size[2] ? 1 : 2);
+        axis_of = (axis_of << 2) | (uint32_t)a;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k == a) { size[k] *= 0.5f; bits[k] += 1; }
+    }
+    const float ext0 = bbox[3] - b0, ext1 = bbox[4] - b1, ext2 = bbox[5] - b2;
+    const float inv0 = ext0 > 0.f ? (float)(1 << bits[0]) / ext0 : 0.f, inv1 = ext1 > 0.f ? (float)(1 << bits[1]) / ext1 : 0.f,
+                inv2 = ext2 > 0.f ? (float)(1 << bits[2]) / ext2 : 0.f;
+    const float top0 = (float)((1 << bits[0]) - 1), top1 = (float)((1 << bits[1]) - 1), top2 = (float)((1 << bits[2]) - 1);
+    auto cell_of = [&](float x, float y, float z) -> uint32_t {
+        const uint32_t q[3] = {(uint32_t)fminf(fmaxf((x - b0) * inv0, 0.f), top0), (uint32_t)fminf(fmaxf((y - b1) * inv1, 0.f), top1),
+                               (uint32_t)fminf(fmaxf((z - b2) * inv2, 0.f), top2)};
+        int left[3] = {bits[0], bits[1], bits[2]};
+        uint32_t key = 0;
+#pragma unroll
+        for (int sbit = 0; sbit < 15; ++sbit) {
+            const int a = (int)((axis_of >> (2 * (14 - sbit))) & 3u);
+            uint32_t bit = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k == a) { left[k] -= 1; bit = (q[k] >> left[k]) & 1u; }
+            key = (key << 1) | bit;
+        }
+        return key;
+    };
+    // 2. counting sort by cell: histogram, exclusive scan, scatter
+    for (int i = tid; i < n; i += TL_T) atomicAdd(&hist[cell_of(xyz[(size_t)i * 3], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2])], 1u);
+    __syncthreads();
+    {
+        constexpr int CPT = TL_CELLS / TL_T;  // 32 consecutive cells per thread
+        uint32_t loc[CPT], sum = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) { loc[c] = sum; sum += hist[tid * CPT + c]; }
+        uint32_t base;
+        TiledScan().exclusive_scan(sum, base, 0u, scan_lds);
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) hist[tid * CPT + c] = base + loc[c];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += TL_T) {
+        const float x = xyz[(size_t)i * 3], y = xyz[(size_t)i * 3 + 1], z = xyz[(size_t)i * 3 + 2];
+        const uint32_t pos = atomicAdd(&hist[cell_of(x, y, z)], 1u);
+        const uint32_t tag = ((0xFFFFu - tl_rank((uint32_t)i)) << 10) | (pos >> 6);  // tie key above the tile id
+        sx[pos] = make_float4(x, y, z, __uint_as_float(tag));
+        st[pos] = temp[i];
+    }
+    for (int i = n + tid; i < np; i += TL_T) {  // padding of the last tile: never selected
+        sx[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+        st[i] = -INFINITY;
+    }
+    __syncthreads();  // workgroup-scope release/acquire: the sorted arrays are visible to every wave (same CU)
+    // 3. every thread owns one tile: box, largest running distance + its key, candidate coordinates.  Tiles are dealt
+    //    round-robin to the waves (lane l of wave w owns tile 16 l + w): a new centre changes a handful of ADJACENT tiles,
+    //    which this way are streamed by different waves in parallel instead of queueing in one
+    const int mytile = lane * (TL_T / 64) + wave;
+    float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
+    float tval = -INFINITY;
+    uint32_t ttag = 0;
+    if (mytile < tiles) {
+        float4 cand = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int e = 0; e < TL_PTS; ++e) {
+            const float4 p = sx[mytile * TL_PTS + e];
+            const float t = st[mytile * TL_PTS + e];
+            const uint32_t tg = __float_as_uint(p.w);
+            if (t != -INFINITY) {  // a real point
+                lox = fminf(lox, p.x); loy = fminf(loy, p.y); loz = fminf(loz, p.z);
+                hix = fmaxf(hix, p.x); hiy = fmaxf(hiy, p.y); hiz = fmaxf(hiz, p.z);
+                if (t > tval || (t == tval && tg > ttag)) { tval = t; ttag = tg; cand = p; }
+            }
+        }
+        tcand[mytile] = cand;
+    }
+    if (tid == 0) {
+        if (lds_idx) sidx[0] = 0;
+        else idxs[0] = 0;
+    }
+    float cx = xyz[0], cy = xyz[1], cz = xyz[2];  // the first centre is point 0
+    int s_cur = 0, s_nxt = 1;
+    uint32_t c_hi = 0, c_lo = 0;
+    __syncthreads();
+
+    for (int j = 1; j < m; ++j) {
+        const float ex = fmaxf(fmaxf(lox - cx, cx - hix), 0.f), ey = fmaxf(fmaxf(loy - cy, cy - hiy), 0.f),
+                    ez = fmaxf(fmaxf(loz - cz, cz - hiz), 0.f);
+        const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(lb < tval);  // an empty tile has tval = -inf
+        const bool touched = j == 1 || todo != 0;
+        while (todo) {
+            // stream up to TL_BATCH of the wave's affected tiles at once (their loads overlap)
+            int tb[TL_BATCH];
+            float4 pv[TL_BATCH];
+            float tv[TL_BATCH];
+#pragma unroll
+            for (int u = 0; u < TL_BATCH; ++u) {
+                tb[u] = todo ? (int)__builtin_ctzll(todo) : -1;
+                if (todo) todo &= todo - 1;
+                if (tb[u] >= 0) {
+                    const int e = (tb[u] * (TL_T / 64) + wave) * TL_PTS + lane;
+                    pv[u] = sx[e];
+                    tv[u] = st[e];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TL_BATCH; ++u) {
+                if (tb[u] < 0) continue;
+                const int tile = tb[u] * (TL_T / 64) + wave;
+                const float d = mcp_sqdist3(pv[u].x, pv[u].y, pv[u].z, cx, cy, cz);
+                const float nt = fminf(d, tv[u]);
+                if (nt != tv[u]) st[tile * TL_PTS + lane] = nt;
+                const uint32_t hi = mcp_ord(nt), tg = __float_as_uint(pv[u].w);
+                const uint32_t whi = mcp_wave_max_u32(hi);
+                const uint32_t wtg = mcp_wave_max_u32(hi == whi ? tg : 0u);
+                if (hi == whi && tg == wtg) tcand[tile] = pv[u];  // exactly one lane (tags are unique per real point)
+                if (lane == tb[u]) { tval = mcp_unord(whi); ttag = wtg; }
+            }
+        }
+        if (touched) {  // the wave's maximum over its 64 tiles
+            const uint32_t hi = mcp_ord(tval);
+            const uint32_t whi = mcp_wave_max_u32(hi);
+            c_lo = mcp_wave_max_u32(hi == whi ? ttag : 0u);
+            c_hi = whi;
+        }
+        if (lane == 0) {
+            const unsigned long long key = ((unsigned long long)c_hi << 32) | c_lo;
+            asm volatile("ds_max_u64 %0, %1" ::"v"((uint32_t)(size_t)&slots[s_cur]), "v"(key) : "memory");
+        }
+        if (tid == 0) slots[s_nxt] = 0ull;
+        __syncthreads();  // also orders this iteration's tcand writes before the read below
+        const uint32_t wlo = (uint32_t)slots[s_cur];
+        const int s_new = 3 - s_cur - s_nxt;
+        s_cur = s_nxt;
+        s_nxt = s_new;
+        const float4 c = tcand[wlo & 1023u];
+        cx = c.x; cy = c.y; cz = c.z;
+        if (tid == 0) {
+            const int old = (int)tl_unrank(0xFFFFu - (wlo >> 10));
+            if (lds_idx) sidx[j] = old;
+            else idxs[j] = old;
+        }
+    }
+    __syncthreads();
+    // running distances back in the caller's order
+    for (int i = tid; i < n; i += TL_T) temp[tl_unrank(0xFFFFu - (__float_as_uint(sx[i].w) >> 10))] = st[i];
+    if (lds_idx) {
+        for (int i = tid; i < m; i += TL_T) idxs[i] = sidx[i];
+    }
+}
+
+int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t s) {
+    const int tiles = (n + TL_PTS - 1) / TL_PTS;
+    const size_t np = (size_t)tiles * TL_PTS;
+    size_t lds = 512 + (size_t)TL_CELLS * 4 + sizeof(typename TiledScan::storage_type);
+    int lds_idx = 0;
+    const size_t after = 512 + (size_t)tiles * sizeof(float4);  // the index list may alias the histogram, not the candidates
+    if (after + (size_t)m * 4 <= 160 * 1024) {
+        lds_idx = (int)after;
+        if (after + (size_t)m * 4 > lds) lds = after + (size_t)m * 4;
+    }
+    if (lds > 160 * 1024) return MCP_ERR_UNSUPPORTED;
+    char *ws = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&ws), (size_t)b * np * (sizeof(float4) + sizeof(float)), s) != hipSuccess) return MCP_ERR_UNSUPPORTED;
+    float4 *sx = reinterpret_cast<float4 *>(ws);
+    float *st = reinterpret_cast<float *>(ws + (size_t)b * np * sizeof(float4));
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(fps_tiled_kernel, dim3(b), dim3(TL_T), lds, s, n, m, tiles, lds_idx, xyz, temp, idx, sx, st);
+    const int rc = mcp_launch_status();
+    (void)hipFreeAsync(ws, s);
+    return rc;
+}
+
 int ref_block_log2(int n) {
     // cuda_utils.h:10-14, same double arithmetic
     int pow_2 = (int)(log((double)n) / log(2.0));
@@ -499,10 +754,6 @@ int launch_spatial_any(int b, int n, int m, int L, const float *xyz, float *temp
     while (ns < n) ns <<= 1;
     const int t = force_t ? force_t : 1024;
     switch (ns / t) {
-#define MCP_FPS_CASE(T, P) \
-    case P:                \
-        if (t == T) return launch_spatial<T, P>(b, n, m, L, xyz, temp, idx, s); \
-        break;
         case 2: if (t == 1024) return launch_spatial<1024, 2>(b, n, m, L, xyz, temp, idx, s); break;
         case 4:
             if (t == 1024) return launch_spatial<1024, 4>(b, n, m, L, xyz, temp, idx, s);
@@ -558,8 +809,11 @@ MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz
             else if (P <= 8) rc = launch_resident<MCP_FPS_T8, MCP_FPS_P8, MCP_FPS_J8, false>(b, n, m, L, xyz, temp, idx, s);
             else if (P <= 16) rc = launch_resident<1024, 16, 0, false>(b, n, m, L, xyz, temp, idx, s);
             else {
-                hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, s, n, m, L, xyz, temp, idx);
-                rc = mcp_launch_status();
+                rc = n <= 65536 ? launch_tiled(b, n, m, xyz, temp, idx, s) : MCP_ERR_UNSUPPORTED;
+                if (rc == MCP_ERR_UNSUPPORTED) {  // beyond the tiled kernel's range: plain streaming, any N
+                    hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, s, n, m, L, xyz, temp, idx);
+                    rc = mcp_launch_status();
+                }
             }
         } else if (bs == 512) rc = launch_resident<512, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
         else if (bs == 256) rc = launch_resident<256, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);

@@ -32,7 +32,7 @@ def test_library_loaded_in_process():
 @pytest.mark.parametrize("b,n,m", [(2, 1024, 256), (2, 8192, 2048), (3, 2048, 512), (2, 512, 256), (2, 256, 64),
                                    (1, 1000, 333), (2, 100, 40), (2, 40, 17), (1, 3, 3), (1, 1024, 2048), (1, 16384, 512),
                                    (1, 20000, 64), (1, 5000, 700), (2, 1025, 100), (1, 12000, 300), (1, 16383, 200),
-                                   (1, 14000, 150)])
+                                   (1, 14000, 150), (1, 40000, 300), (1, 70000, 40)])
 def test_fps_bit_exact(b, n, m):
     xyz = cloud(100 + n, b, n)
     want = orc.furthest_point_sample(xyz, m)

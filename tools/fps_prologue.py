@@ -13,3 +13,9 @@ def t(fn, reps=9):
 for n in (8192, 2048):
     c = a[:, :n].contiguous()
     print(n, "m=2", t(lambda: be.fps(c, 2)), "m=34", t(lambda: be.fps(c, 34)), "m=66", t(lambda: be.fps(c, 66)))
+g = torch.Generator().manual_seed(0)
+big = ((torch.rand(8, 65536, 3, generator=g) * 2 - 1) * torch.tensor([80.0, 80.0, 6.0])).cuda().contiguous()
+x1b, x2b, _ = synth.make_batch(2, 4, 65536, device="cuda")
+lidar = torch.cat([x1b, x2b]).transpose(1, 2).contiguous()
+for name, c in (("uniform box", big), ("lidar-like", lidar)):
+    print(f"65536 {name}: m=2 {t(lambda: be.fps(c, 2), 3):.0f} us  m=258 {t(lambda: be.fps(c, 258), 3):.0f} us  m=2048 {t(lambda: be.fps(c, 2048), 3):.0f} us")
