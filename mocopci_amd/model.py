@@ -46,6 +46,37 @@ def _dtype(name):
     return getattr(torch, name)
 
 
+class Early:
+    """Results that depend only on encoder outputs (EI cross-formers, feature-cosine searches, the level-0 interpolation
+    search) are issued on a third stream the moment their inputs exist; the small-kernel stages of the encoder's lower levels
+    and of the decoder's levels 3 and 2 leave most of the chip idle, and these branches fill it.  get() makes the caller's
+    stream wait for the one result it is about to read.  Without a GPU stream (CPU backends) everything runs inline."""
+
+    def __init__(self, model, device):
+        self.aux = model.side_stream(device, 1)
+        self.main = torch.cuda.current_stream(device) if self.aux is not None else None
+        self.items = {}
+
+    def launch(self, key, fn):
+        if self.aux is None:
+            self.items[key] = (fn(), None)
+            return
+        self.aux.wait_stream(self.main)  # inputs were produced on the main stream
+        with torch.cuda.stream(self.aux):
+            res = fn()
+            ev = torch.cuda.Event()
+            ev.record(self.aux)
+        for t in (res if isinstance(res, (tuple, list)) else (res,)):
+            t.record_stream(self.main)
+        self.items[key] = (res, ev)
+
+    def get(self, key):
+        res, ev = self.items[key]
+        if ev is not None:
+            self.main.wait_event(ev)
+        return res
+
+
 class MoCoPCI(nn.Module):
     T_F = [0.0, 0.41666666666666663, 0.5, 0.5833333333333333, 1.0]  # mocopci.py:824
     T_B = [1.0, 0.5833333333333333, 0.5, 0.41666666666666663, 0.0]  # mocopci.py:825
@@ -142,19 +173,20 @@ class MoCoPCI(nn.Module):
         are moved as raw 32-bit words."""
         return ops.backend().group_rows(idx_self.view(torch.float32), sel).view(torch.int32)
 
-    def side_stream(self, device):
-        """Second HIP stream for the serial FPS chains (one workgroup per batch element, latency-bound): they
-        overlap with the KNN / PointConv work of the main stream.  One side stream per caller stream, so forwards
-        issued on different streams stay independent.  CPU backends run inline."""
+    def side_stream(self, device, which=0):
+        """Extra HIP streams beside the caller's.  0: the serial FPS chains (one workgroup per batch element, latency-
+        bound), which overlap with the KNN / PointConv work of the main stream.  1: branches that depend only on encoder
+        features (see Early).  One set per caller stream, so forwards issued on different streams stay independent.
+        CPU backends run inline."""
         if device.type != "cuda":
             return None
-        key = (device.index, torch.cuda.current_stream(device).stream_id)
+        key = (device.index, torch.cuda.current_stream(device).stream_id, which)
         sides = self.__dict__.setdefault("_sides", {})
         if key not in sides:
             sides[key] = torch.cuda.Stream(device=device)
         return sides[key]
 
-    def run_encoder(self, xyz):
+    def run_encoder(self, xyz, early=None):
         """PointConvEncoder.forward (mocopci.py:438-468), color == xyz.  The four FPS levels depend only on the
         coordinates, so the whole sampling pyramid is issued up front on the side stream."""
         p = "encoder."
@@ -193,14 +225,29 @@ class MoCoPCI(nn.Module):
         # level 1 searches the 32 nearest of pc1 = xyz[sel1] in xyz: rows of the level-0 self search
         f1 = self.pointconv(p + "level1", xyz, pc1, f0_1, idx=self.sampled_neighbours(idx0, sel1))
         f1 = self.conv1d_block(f1, p + "level1_0")
+        B = xyz.shape[0] // 2
+        d = "multi_frame_inference."
+        swap = lambda t: torch.cat([t[B:], t[:B]], dim=0)
+
+        def branches(lvl, f):  # decoder work that needs nothing but this level's encoder features (both frames stacked)
+            if early is None:
+                return
+            early.launch(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:])))
+            early.launch(("cos", lvl), lambda: ops.backend().knn_cosine(f, swap(f), 16))
+
+        branches(1, f1)
+        if early is not None:
+            early.launch("i3_01", lambda: ops.backend().interp3_search(xyz, pc1))
         f1_2 = self.conv1d_block(f1, p + "level1_1")
         need(2)
         f2 = self.pointconv(p + "level2", pc1, pc2, f1_2)
         f2 = self.conv1d_block(f2, p + "level2_0")
+        branches(2, f2)
         f2_3 = self.conv1d_block(f2, p + "level2_1")
         need(3)
         f3 = self.pointconv(p + "level3", pc2, pc3, f2_3)
         f3 = self.conv1d_block(f3, p + "level3_0")
+        branches(3, f3)
         f3_4 = self.conv1d_block(f3, p + "level3_1")
         need(4)
         f4 = self.pointconv(p + "level4", pc3, pc4, f3_4)
@@ -368,7 +415,7 @@ class MoCoPCI(nn.Module):
             self._time_cache[key] = enc.to(device)
         return self._time_cache[key]
 
-    def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None):
+    def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None, idx_c12=None):
         """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C)."""
         c1 = torch.cat([f1_0, f1_1, f1_new], dim=-1)
         c2 = torch.cat([f2_0, f2_1, f2_new], dim=-1)
@@ -382,7 +429,8 @@ class MoCoPCI(nn.Module):
         # coordinates: one search serves all nine cross() calls of this level.  The batch holds both decoder
         # directions, so the (f2_0 -> f1_0) search is the same result with its halves swapped.
         half = f1_0.shape[0] // 2
-        idx_c12 = ops.backend().knn_cosine(f1_0, f2_0, 16)
+        if idx_c12 is None:
+            idx_c12 = ops.backend().knn_cosine(f1_0, f2_0, 16)
         idx_c21 = torch.cat([idx_c12[half:], idx_c12[:half]], dim=0)
         # The loop over the 3 upsampled flows (mocopci.py:191-197) has no carried dependency -- the bid/fe layers always
         # see the original c_feat1/c_feat2 -- so the three iterations run as one batch of 3 x (2B); feat1_new/feat2_new
@@ -471,10 +519,10 @@ class MoCoPCI(nn.Module):
         cache = {}
 
         # EI cross-formers (mocopci.py:830-836): fusion features are shared by both frames
-        fus = [None]
-        for lvl, name in ((1, "ei1"), (2, "ei2"), (3, "ei3")):
-            f = self.ei_crossformer(m + name, feats[lvl][:B], feats[lvl][B:])
-            fus.append(torch.cat([f, f], dim=0))
+        # EI cross-formers (mocopci.py:830-836; fusion features shared by both frames), the feature-cosine searches and the
+        # level-0 interpolation search were issued by the encoder as soon as their inputs existed (Early)
+        early = self._early
+        fus = [None] + [early.get(("fus", 3)) if lvl == 3 else None for lvl in (1, 2, 3)]
 
         # l4 -> l3 (mocopci.py:842-845)
         f_l4_3 = self.conv1d_block(self.interp(pcs[3], pcs[4], feats[4], cache, "43"), m + "deconv4_3")
@@ -483,7 +531,7 @@ class MoCoPCI(nn.Module):
         # cross3 (pointconv_util.py:783-791): rows [:B] give feat1_new, rows [B:] give feat2_new
         x = m + "cross3"
         new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(c3_o, x + ".cross_t22"), feats[3],
-                          feats_o[3], x + ".pos1", [x + ".mlp1.0"], False)
+                          feats_o[3], x + ".pos1", [x + ".mlp1.0"], False, idx_c=early.get(("cos", 3)))
         new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
         # cross_block3, both directions at once (mocopci.py:853-856)
         xs = torch.stack([new3, sw(new3)], dim=1)                                  # (2B,2,N3,C)
@@ -500,8 +548,9 @@ class MoCoPCI(nn.Module):
         C = feats[2].shape[-1]
         te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
                        dim=0).unsqueeze(2)                                          # (2B,5,1,C)
+        fus[2] = early.get(("fus", 2))
         frame2s, n1_2, n2_2 = self.multiframe_attention(m + "multi_frame_up_2", pcs[2], pcs_o[2], f_l3_2, sw(f_l3_2), feats[2], fus[2],
-                                                        feats_o[2], fus[2], ups, te)                    # (2B,3,N2,3)
+                                                        feats_o[2], fus[2], ups, te, idx_c12=early.get(("cos", 2)))  # (2B,3,N2,3)
         # l2 -> l1 (mocopci.py:920-927): the forward branch upsamples (feat1_new_f -> pc1, feat2_new_f -> pc2),
         # the backward branch (feat1_new_b -> pc1, feat2_new_b -> pc2) where *_b come from the swapped call.
         f1_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n1_2[:B], n2_2[:B]], 0), cache, "21"), m + "deconv2_1")
@@ -516,13 +565,14 @@ class MoCoPCI(nn.Module):
         # l0 (mocopci.py:997-1053).  Output frames 0,1 use the forward branch (flow index i on frame 1);
         # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).  Of the level-1 flows
         # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.
+        fus[1] = early.get(("fus", 1))
         flow_src = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
-                                             feats_o[1], fus[1], ups, te, rows=rows1)[0].contiguous()    # (3B,N1,3)
+                                             feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=early.get(("cos", 1)))[0].contiguous()  # (3B,N1,3)
         pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
         f0 = torch.cat([feats[0][:B], feats[0][:B], feats[0][B:]], dim=0)
         # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
         # (2B rows), its rows repeated for the 3B arrangement
-        i3, w3 = ops.backend().interp3_search(pcs[0], pcs[1])
+        i3, w3 = early.get("i3_01")
         rep3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
         up_flow = ops.backend().interp3_apply(flow_src, rep3(i3), rep3(w3))        # (3B,N,3)
         warped = pc0 + up_flow
@@ -559,5 +609,6 @@ class MoCoPCI(nn.Module):
         B = xyz1.shape[0]
         xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
         with torch.no_grad():
-            pcs, feats = self.run_encoder(xyz)
+            self._early = Early(self, xyz.device)
+            pcs, feats = self.run_encoder(xyz, self._early)
             return self.run_decoder(pcs, feats, B)
