@@ -53,19 +53,21 @@ class Early:
     stream wait for the one result it is about to read.  Without a GPU stream (CPU backends) everything runs inline."""
 
     def __init__(self, model, device):
-        self.aux = model.side_stream(device, 1)
-        self.main = torch.cuda.current_stream(device) if self.aux is not None else None
+        self.model, self.device = model, device
+        self.main = torch.cuda.current_stream(device) if device.type == "cuda" else None
         self.items = {}
 
-    def launch(self, key, fn):
-        if self.aux is None:
+    def launch(self, key, fn, lane=1):
+        """lane: which extra stream (one per pyramid level, so a level's branches never queue behind another level's)."""
+        aux = self.model.side_stream(self.device, lane)
+        if aux is None:
             self.items[key] = (fn(), None)
             return
-        self.aux.wait_stream(self.main)  # inputs were produced on the main stream
-        with torch.cuda.stream(self.aux):
+        aux.wait_stream(self.main)  # inputs were produced on the main stream
+        with torch.cuda.stream(aux):
             res = fn()
             ev = torch.cuda.Event()
-            ev.record(self.aux)
+            ev.record(aux)
         for t in (res if isinstance(res, (tuple, list)) else (res,)):
             t.record_stream(self.main)
         self.items[key] = (res, ev)
@@ -232,12 +234,12 @@ class MoCoPCI(nn.Module):
         def branches(lvl, f):  # decoder work that needs nothing but this level's encoder features (both frames stacked)
             if early is None:
                 return
-            early.launch(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:])))
-            early.launch(("cos", lvl), lambda: ops.backend().knn_cosine(f, swap(f), 16))
+            early.launch(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:])), lane=lvl)
+            early.launch(("cos", lvl), lambda: ops.backend().knn_cosine(f, swap(f), 16), lane=lvl)
 
         branches(1, f1)
         if early is not None:
-            early.launch("i3_01", lambda: ops.backend().interp3_search(xyz, pc1))
+            early.launch("i3_01", lambda: ops.backend().interp3_search(xyz, pc1), lane=1)
         f1_2 = self.conv1d_block(f1, p + "level1_1")
         need(2)
         f2 = self.pointconv(p + "level2", pc1, pc2, f1_2)
