@@ -249,7 +249,6 @@ class MoCoPCI(nn.Module):
         need(3)
         f3 = self.pointconv(p + "level3", pc2, pc3, f2_3)
         f3 = self.conv1d_block(f3, p + "level3_0")
-        branches(3, f3)
         f3_4 = self.conv1d_block(f3, p + "level3_1")
         need(4)
         f4 = self.pointconv(p + "level4", pc3, pc4, f3_4)
@@ -390,6 +389,14 @@ class MoCoPCI(nn.Module):
         frames = self.lin(xf, prefix + ".mapping_xyz")                            # (B,3,N,3)
         return xf, frames
 
+    def index_tensor(self, values, device):
+        """int64 device tensor of a small static index list, built once (no host-to-device copy inside the forward)."""
+        key = ("index", tuple(values), str(device))
+        self.__dict__.setdefault("_time_cache", {})
+        if key not in self._time_cache:
+            self._time_cache[key] = torch.tensor(values, device=device)
+        return self._time_cache[key]
+
     def area_matrix(self, n_in, n_out, device):
         """F.interpolate(mode="area") = adaptive average pooling along the last axis, as an (n_in, n_out) matrix: output j
         averages inputs floor(j*n_in/n_out) .. ceil((j+1)*n_in/n_out)-1.  (3 -> 32: one or two inputs per output, so the
@@ -446,8 +453,8 @@ class MoCoPCI(nn.Module):
             # pairs with, (b, f) <-> (b, R-1-f); the other members of the 3 x (2B) batch are dropped
             need = sorted({f * B2 + b for b, f in (divmod(i, R) for i in rows)} | {(R - 1 - f) * B2 + b for b, f in (divmod(i, R) for i in rows)})
             if len(need) < R * B2:
-                sel = torch.tensor(need, device=dev)
-            rows = torch.tensor(rows, device=dev)
+                sel = self.index_tensor(need, dev)
+            rows = self.index_tensor(rows, dev)
         expand = lambda t: t.unsqueeze(0).expand(R, *t.shape).reshape(R * t.shape[0], *t.shape[1:])
         rep = expand if sel is None else (lambda t: expand(t)[sel])
         pick = (lambda t: t) if sel is None else (lambda t: t[sel])
@@ -523,8 +530,10 @@ class MoCoPCI(nn.Module):
         # EI cross-formers (mocopci.py:830-836): fusion features are shared by both frames
         # EI cross-formers (mocopci.py:830-836; fusion features shared by both frames), the feature-cosine searches and the
         # level-0 interpolation search were issued by the encoder as soon as their inputs existed (Early)
+        # (level 3's own are needed right here, so they run inline)
         early = self._early
-        fus = [None] + [early.get(("fus", 3)) if lvl == 3 else None for lvl in (1, 2, 3)]
+        f3 = self.ei_crossformer(m + "ei3", feats[3][:B], feats[3][B:])
+        fus = [None, None, None, torch.cat([f3, f3], dim=0)]
 
         # l4 -> l3 (mocopci.py:842-845)
         f_l4_3 = self.conv1d_block(self.interp(pcs[3], pcs[4], feats[4], cache, "43"), m + "deconv4_3")
@@ -533,7 +542,7 @@ class MoCoPCI(nn.Module):
         # cross3 (pointconv_util.py:783-791): rows [:B] give feat1_new, rows [B:] give feat2_new
         x = m + "cross3"
         new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(c3_o, x + ".cross_t22"), feats[3],
-                          feats_o[3], x + ".pos1", [x + ".mlp1.0"], False, idx_c=early.get(("cos", 3)))
+                          feats_o[3], x + ".pos1", [x + ".mlp1.0"], False)
         new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
         # cross_block3, both directions at once (mocopci.py:853-856)
         xs = torch.stack([new3, sw(new3)], dim=1)                                  # (2B,2,N3,C)
