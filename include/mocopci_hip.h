@@ -110,7 +110,7 @@ int mcp_knn(int b, int q, int n, int k, int dist_form, const float *query, const
  *   mcp_knn_pruned:   query_sorted (B,Q,3) with qperm (B,Q) = original row of each sorted query (NULL = identity),
  *                     ref_sorted (B,N,3) with rperm (B,N) = original index of each sorted reference, boxes as above
  *                     -> idx (B,Q,K) ORIGINAL reference indices at ORIGINAL query rows (+ dist).  1 <= K <= 32, N <= 65536.
- *   mcp_build_cloud:  all of the above in one launch for N <= 16384 (bbox, isotropic Morton keys, in-LDS sort, gather,
+ *   mcp_build_cloud:  all of the above in one launch for N <= 16384 (bbox, isotropic Morton keys, block radix sort, gather,
  *                     tile boxes): xyz (B,N,3) -> sorted_xyz (B,N,3), perm (B,N) int32, boxes (B,ceil(N/tile),6). */
 int mcp_knn_tile_size(void); /* references per box tile (64): boxes arrays have ceil(N / tile) rows */
 int mcp_build_cloud(int b, int n, const float *xyz, float *sorted_xyz, int *perm, float *boxes, mcp_stream_t stream);

@@ -2,20 +2,20 @@
 //
 // Same result definition as knn.hip / the oracle (K smallest under (distance, index), ascending,
 // distances in the shared fp32 canon), but the reference cloud is visited selectively:
-//   * host side (mocopci_amd/ops.py) Morton-sorts queries and references once per cloud;
-//     mcp_morton_codes / mcp_tile_boxes below produce the sort keys and one axis-aligned box
-//     per tile of PT consecutive sorted references;
-//   * a wave owns 64 consecutive SORTED queries (a compact region), computes the lower bound of the
-//     squared distance from its query box to every tile box, and visits tiles in ascending bound
-//     order; it stops as soon as the smallest unvisited bound exceeds the largest per-lane K-th
-//     distance plus a slack that covers the rounding of the distance expression -- every skipped
-//     reference would have failed the per-lane "d <= tau" test anyway, so the output is bit-identical
-//     to the exhaustive scan;
-//   * within a visited tile the scan / threshold queue / register bitonic merge are those of
-//     knn.hip; candidates carry the ORIGINAL reference index (tie order is defined on it), and
-//     "d <= tau" (not "<") is used because tiles are no longer visited in index order;
+//   * queries and references are Morton-sorted once per cloud (mcp_build_cloud: one launch per cloud up to 16384 points;
+//     mcp_morton_codes / mcp_tile_boxes for larger ones, with the sort left to the caller), with one axis-aligned box per
+//     tile of PT consecutive sorted references;
+//   * a wave owns 16 consecutive SORTED queries (a compact region) x 4 lanes each, computes the lower bound of the
+//     squared distance from its query box to every tile box, and visits tiles in ascending bound order; it stops as soon
+//     as the smallest unvisited bound exceeds the largest per-lane K-th distance plus a slack that covers the rounding of
+//     the distance expression, and skips a tile no query of the wave can use (point-to-box test) -- every skipped
+//     reference would have failed the per-lane "d <= tau" test anyway, so the output is bit-identical to the exhaustive
+//     scan;
+//   * within a visited tile the scan / threshold queue / register bitonic merge are those of knn.hip; candidates carry
+//     the ORIGINAL reference index (tie order is defined on it), and "d <= tau" (not "<") is used because tiles are no
+//     longer visited in index order;
 //   * results are written to the query's original row (qperm).
-// At N=8192 a wave scans ~1300 of the 8192 references (64-point tiles measured 5-7 % faster than 128/256).
+// At N=8192 a wave scans ~900 of the 8192 references (64-point tiles measured 5-7 % faster than 128/256).
 #include <stdlib.h>
 
 #include <rocprim/block/block_radix_sort.hpp>
