@@ -103,7 +103,7 @@ class HipBackend:
     PRUNE_MIN_QUERIES = int(os.environ.get("MCP_PRUNE_MIN_QUERIES", "1024"))
 
     def __init__(self):
-        self._clouds = []  # [(weakref(tensor), version, sorted_cloud)], most recent last
+        self._clouds = []  # [(weakref(tensor), version, sorted_cloud, stream, built-event)], most recent last
         self._tile = None
 
     @property
@@ -115,8 +115,13 @@ class HipBackend:
     def _sorted_cloud(self, xyz):
         """Morton order of a cloud: (sorted xyz, perm int32, tile boxes).  Cached per tensor OBJECT (weakref +
         version counter), because the harness searches the same clouds many times per forward."""
-        for ref, ver, cloud in reversed(self._clouds):
+        cur = torch.cuda.current_stream(xyz.device) if xyz.is_cuda else None
+        for ref, ver, cloud, stream, done in reversed(self._clouds):
             if ref() is xyz and ver == xyz._version:
+                if cur is not None and stream != cur:  # built on another stream of this forward: order + lifetime
+                    cur.wait_event(done)
+                    for t in cloud:
+                        t.record_stream(cur)
                 return cloud
         B, N, _ = xyz.shape
         tiles = (N + self.TILE - 1) // self.TILE
@@ -133,8 +138,12 @@ class HipBackend:
             sorted_xyz = self.group_rows(xyz, perm)
             _call("mcp_tile_boxes", xyz, B, N, _lib.fptr(sorted_xyz), _lib.fptr(boxes))
         cloud = (sorted_xyz, perm, boxes)
+        done = None
+        if cur is not None:
+            done = torch.cuda.Event()
+            done.record(cur)
         self._clouds = [e for e in self._clouds if e[0]() is not None][-7:]
-        self._clouds.append((weakref.ref(xyz), xyz._version, cloud))
+        self._clouds.append((weakref.ref(xyz), xyz._version, cloud, cur, done))
         return cloud
 
     def knn(self, query, ref, k, mode=MCP_DIST_EXPANSION, return_dist=False):
