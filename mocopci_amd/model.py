@@ -622,13 +622,16 @@ class MoCoPCI(nn.Module):
             x_all = self.lin(dfeat_all, t + ".fc1")
             proj_all = [self.lin(x_all, t + w) for w in (".w_qs", ".w_ks", ".w_vs")]
             main.wait_event(done)
+            # the 3-NN search of the upsampling below needs only (warped, down): it runs beside the Point-Transformer kernel
+            early.launch("i3_refine", lambda: be.interp3_search(warped, down), lane=1)
             dfeat = be.group_rows(dfeat_all, sel)
             shape = self.transformer_block(t, dfeat, down, qkv=[be.group_rows(v, sel) for v in proj_all])
+            upf = be.interp3_apply(shape, *early.get("i3_refine"))
         else:
             # down = warped[sel]: its 32 nearest in warped are rows of the self search the fusion stage needs anyway
             dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel))
             shape = self.transformer_block(m + "shape1", dfeat, down)
-        upf = ops.backend().interp3(warped, down, shape)
+            upf = ops.backend().interp3(warped, down, shape)
         refine = self.lin(F.relu(self.lin(upf, m + "pred.0")), m + "pred.2")       # (3B,N,3)
         final = self.fusion(warped, refine, idx_self=idx_self)
         return [final[:B], final[B:2 * B], final[2 * B:]]
