@@ -533,8 +533,9 @@ class MoCoPCI(nn.Module):
         m = "multi_frame_inference."
         dev = pcs[0].device
         sw = lambda t: torch.cat([t[B:], t[:B]], dim=0)                            # swap the two frames
-        pcs_o = [sw(p) for p in pcs]                                               # "other" frame, same order
-        feats_o = [sw(f) for f in feats]
+        # "other" frame, same order (levels 1..3 are the ones read)
+        pcs_o = [sw(p) if 1 <= i <= 3 else None for i, p in enumerate(pcs)]
+        feats_o = [sw(f) if 1 <= i <= 3 else None for i, f in enumerate(feats)]
         cache = {}
 
         # EI cross-formers (mocopci.py:830-836): fusion features are shared by both frames
