@@ -193,8 +193,8 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline():
-    """The same graph on host cores: oracle backend ("port"), ONE sequence of the same workload."""
+def cpu_baseline(batch=B_PER_GPU):
+    """The same graph on host cores: oracle backend ("port"), one full batch of the same workload (about 10-20 s)."""
     from mocopci_amd import ops, synth
     from mocopci_amd.model import MoCoPCI
     from oracle.backend import OracleBackend
@@ -204,7 +204,7 @@ def cpu_baseline():
     torch.set_num_threads(cores)
     net = MoCoPCI()
     net.load_state_dict(synth.weights_by_name(net._spec), strict=True)
-    x1, x2, _ = synth.make_batch(2, 1, NPOINTS)
+    x1, x2, _ = synth.make_batch(2, batch, NPOINTS)
     from oracle import pointset as orc
     orc.lib().orc_set_threads(cores)
     prev = ops.set_backend(OracleBackend())
@@ -214,8 +214,8 @@ def cpu_baseline():
         dt = time.perf_counter() - t0
     finally:
         ops.set_backend(prev)
-    return {"value": 3.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 sequence (N={NPOINTS}) of the same workload, one forward = 3 frames, {dt:.1f} s; "
+    return {"value": 3.0 * batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"one step of the same workload ({batch} sequences, N={NPOINTS}, {3 * batch} frames), {dt:.1f} s; "
                       "C oracle point-set ops (OpenMP) + torch-CPU dense ops"}
 
 
