@@ -32,3 +32,26 @@ def test_forward_full_size_runs_and_is_deterministic():
     for u, v in zip(a, b):
         assert u.shape == (2, 8192, 3) and torch.isfinite(u).all()
         assert torch.equal(u, v)
+
+
+def test_forward_full_size_matches_the_oracle_backend():
+    """BASELINE configs[1] point count (N=8192), one sequence: the HIP graph against the same graph on the CPU oracle backend
+    (C restatement of the point-set operators + torch-CPU dense ops).  Exact for the sampled pyramids; the frames agree
+    element-wise up to near-tie neighbour flips (<= 5 % of coordinates, as for the reference fixtures) and their Chamfer
+    distance to the synthetic ground truth within the north-star tolerance, 1e-5 relative."""
+    from mocopci_amd import synth
+    from oracle.backend import OracleBackend
+    x1, x2, gt = synth.make_batch(2, 1, 8192, device="cuda:0")
+    got = hc.build_model("cuda:0")(x1, x2)
+    cpu_net = hc.build_model("cpu")
+    prev = ops.set_backend(OracleBackend())
+    try:
+        want = cpu_net(x1.cpu(), x2.cpu())
+    finally:
+        ops.set_backend(prev)
+    be = ops.backend()
+    for j, (g, w) in enumerate(zip(got, want)):
+        hc.close(f"full.out{j}", g, w.numpy(), outlier_frac=0.05)
+        cg = float(be.chamfer(g.contiguous(), gt[j]))
+        cw = float(be.chamfer(w.to("cuda:0").contiguous(), gt[j]))
+        assert abs(cg - cw) <= 1e-5 * abs(cw), (j, cg, cw)
