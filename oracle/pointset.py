@@ -35,14 +35,23 @@ def lib():
     return _lib
 
 
+class _Ptr:
+    """Pointer argument that keeps its tensor alive for the duration of the call: `_f(x.contiguous())` may be handed a
+    temporary, and a bare c_void_p would let it be freed before the C function reads it."""
+
+    def __init__(self, t):
+        self.t = t
+        self._as_parameter_ = ctypes.c_void_p(t.data_ptr())
+
+
 def _f(t):
     assert t.dtype == torch.float32 and t.is_contiguous() and t.device.type == "cpu"
-    return ctypes.c_void_p(t.data_ptr())
+    return _Ptr(t)
 
 
 def _i(t):
     assert t.dtype == torch.int32 and t.is_contiguous() and t.device.type == "cpu"
-    return ctypes.c_void_p(t.data_ptr())
+    return _Ptr(t)
 
 
 def opt_n_threads(n):

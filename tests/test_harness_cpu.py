@@ -28,6 +28,11 @@ def test_forward_batched_matches_reference(oracle_backend):
     hc.run_forward_check("cpu", "forward_b2_n2048", 6, 2, 2048, orc.chamfer)
 
 
+def test_forward_baseline_point_count_matches_reference(oracle_backend):
+    """BASELINE configs[1]'s point count (N=8192, sequence 0 of config 2) against the reference's own forward."""
+    hc.run_forward_check("cpu", "forward_c2_n8192", 2, 1, 8192, orc.chamfer)
+
+
 def test_state_dict_keys_match_reference_spec():
     import json, os
     spec = json.load(open(os.path.join(hc.GOLD, "state_dict_spec.json")))

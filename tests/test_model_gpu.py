@@ -22,6 +22,11 @@ def test_forward_batched_on_gpu():
     hc.run_forward_check("cuda:0", "forward_b2_n2048", 6, 2, 2048, ops.backend().chamfer)
 
 
+def test_forward_baseline_point_count_on_gpu():
+    """BASELINE configs[1]'s point count (N=8192, sequence 0 of config 2) against the REFERENCE'S stored forward."""
+    hc.run_forward_check("cuda:0", "forward_c2_n8192", 2, 1, 8192, ops.backend().chamfer)
+
+
 def test_forward_full_size_runs_and_is_deterministic():
     # config 2 shape at B=2 (N=8192): two runs give identical output (no atomics on the forward path)
     from mocopci_amd import synth
