@@ -60,6 +60,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Invoked plainly (`python bench.py --gpus N`): fan out to one fresh rank process per GPU, as the reference's only
+        # multi-GPU mechanism does with threads (nn.DataParallel, train.py:73-80).  This process has not touched the GPU
+        # (no torch.cuda call yet) and never will: it only relays rank 0's JSON line and the launcher's exit code.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,6 +146,7 @@ def main():
         "value": total_frames / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
+        "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
@@ -191,6 +197,19 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n, argv):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv> as a child process; returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(batch=B_PER_GPU):

@@ -22,6 +22,8 @@
 #ifndef MOCOPCI_HIP_H
 #define MOCOPCI_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -44,9 +46,18 @@ const char *mcp_error_string(int code);
  * kernel sampling_gpu.cu:93-253.  xyz (B,N,3); temp (B,N) scratch pre-filled with 1e10 by the
  * caller (pointnet2_utils.py:26), holds the final min-distances on return; idx (B,M) int32.
  * Bit-exact with the reference kernel's index sequence including its tie rule.
- * 16384 < N <= 65536 takes B*ceil(N/64)*64*20 bytes of scratch from the stream-ordered allocator (hipMallocAsync /
- * hipFreeAsync on `stream`) for the duration of the call; every other size uses no memory beyond the arguments. */
+ * No memory beyond the arguments is used.  For 16384 < N <= 65536 the fast (tiled, spatially pruned) kernel needs scratch
+ * for a sorted copy of the cloud: pass it through mcp_furthest_point_sampling_ws; this entry point, which keeps the reference
+ * wrapper's exact argument list, then runs the plain streaming kernel (same indices, ~9x slower at 8 x 65536 -> 2048). */
 int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx, mcp_stream_t stream);
+
+/* Same operation with caller-provided scratch (any workspace is a caller pointer + a size query).
+ * mcp_fps_workspace_bytes returns how many bytes this (b, n, m) can use -- 0 when the size needs none -- and
+ * mcp_furthest_point_sampling_ws takes a device buffer of at least that size (NULL / too small: behaves like
+ * mcp_furthest_point_sampling).  The buffer is only used during the call (stream-ordered). */
+size_t mcp_fps_workspace_bytes(int b, int n, int m);
+int mcp_furthest_point_sampling_ws(int b, int n, int m, const float *xyz, float *temp, int *idx, void *workspace,
+                                   size_t workspace_bytes, mcp_stream_t stream);
 
 /* gather_points_wrapper(b,c,n,npoints,points,idx,out)      sampling.cpp:11-22, sampling_gpu.cu:8-44
  * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */

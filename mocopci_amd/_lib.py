@@ -19,6 +19,8 @@ SIGNATURES = {
     "mcp_abi_version": [],
     "mcp_error_string": [_i],
     "mcp_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
+    "mcp_fps_workspace_bytes": [_i, _i, _i],
+    "mcp_furthest_point_sampling_ws": [_i, _i, _i, _p, _p, _p, _p, ctypes.c_size_t, _p],
     "mcp_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_group_points": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
@@ -55,7 +57,7 @@ SIGNATURES = {
     "mcp_prof_enable": [_i],
     "mcp_prof_collect": [_i, _p, _p],
 }
-_RESTYPES = {"mcp_error_string": ctypes.c_char_p}
+_RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

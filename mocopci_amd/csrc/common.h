@@ -67,6 +67,20 @@ void mcp_prof_end(int kernel_id, hipStream_t s);
         if (!(cond)) return MCP_ERR_BAD_ARG; \
     } while (0)
 
+// hipFuncSetAttribute applies to the CURRENT device, so "done" is remembered per device (one process may drive several
+// GPUs, e.g. under nn.DataParallel, train.py:73-80).  Racing threads at worst repeat the idempotent call.
+struct McpPerDeviceOnce {
+    unsigned long long done = 0ull;
+    bool need() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (__atomic_load_n(&done, __ATOMIC_RELAXED) & bit) return false;
+        __atomic_fetch_or(&done, bit, __ATOMIC_RELAXED);
+        return true;
+    }
+};
+
 static inline int mcp_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MCP_OK : (int)e;

@@ -216,10 +216,9 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
                  const int *idx, const float *packed, float *out, hipStream_t s) {
     const size_t lds = CrossLds<D>::FLOATS * sizeof(float);
     auto kern = cross_kernel<D>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     // at least 8 points per wave so the weight staging is amortised
     const long long want = (total + WAVES * 8 - 1) / (WAVES * 8);

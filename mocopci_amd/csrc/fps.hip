@@ -666,7 +666,13 @@ __global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles
     }
 }
 
-int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t s) {
+size_t tiled_workspace_bytes(int b, int n) {
+    const size_t np = (size_t)((n + TL_PTS - 1) / TL_PTS) * TL_PTS;
+    return (size_t)b * np * (sizeof(float4) + sizeof(float));
+}
+
+// ws: caller-provided scratch of at least tiled_workspace_bytes(b, n) bytes (the library never allocates)
+int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, char *ws, hipStream_t s) {
     const int tiles = (n + TL_PTS - 1) / TL_PTS;
     const size_t np = (size_t)tiles * TL_PTS;
     size_t lds = 512 + (size_t)TL_CELLS * 4 + sizeof(typename TiledScan::storage_type);
@@ -677,19 +683,14 @@ int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, h
         if (after + (size_t)m * 4 > lds) lds = after + (size_t)m * 4;
     }
     if (lds > 160 * 1024) return MCP_ERR_UNSUPPORTED;
-    char *ws = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&ws), (size_t)b * np * (sizeof(float4) + sizeof(float)), s) != hipSuccess) return MCP_ERR_UNSUPPORTED;
     float4 *sx = reinterpret_cast<float4 *>(ws);
     float *st = reinterpret_cast<float *>(ws + (size_t)b * np * sizeof(float4));
-    static bool attr_done = false;
-    if (!attr_done) {
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(fps_tiled_kernel, dim3(b), dim3(TL_T), lds, s, n, m, tiles, lds_idx, xyz, temp, idx, sx, st);
-    const int rc = mcp_launch_status();
-    (void)hipFreeAsync(ws, s);
-    return rc;
+    return mcp_launch_status();
 }
 
 int ref_block_log2(int n) {
@@ -706,10 +707,9 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
     const size_t xyz_bytes = (size_t)n * 3 * sizeof(float);
     if (xyz_bytes + slot_bytes <= 150 * 1024) {
         auto kern = fps_resident_kernel<T, P, J, GENERIC, true>;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static McpPerDeviceOnce attr_once;
+        if (attr_once.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
         }
         hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + xyz_bytes, s, n, m, L, xyz, temp, idx);
     } else {
@@ -728,13 +728,12 @@ int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, in
         lds_idx = (int)lds;
         lds += (size_t)m * 4;
     }
-    static bool attr_done = false;  // benign race: the attribute is idempotent
-    if (!attr_done) {
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
-        attr_done = true;
     }
     (void)L;  // n >= 1024: the reference block size is 1024 (asserted by the caller)
     if (lds_xyz) hipLaunchKernelGGL((fps_spatial_kernel<T, P, true>), dim3(b), dim3(T), lds, s, n, m, lds_idx, xyz, temp, idx);
@@ -788,10 +787,10 @@ extern "C" __attribute__((visibility("default"))) int mcp_fps_diag_read(unsigned
 }
 #endif
 
-MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx, mcp_stream_t stream) {
-    MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && temp && idx);
-    if (m <= 0) return MCP_OK;  // sampling_gpu.cu:100
-    hipStream_t s = (hipStream_t)stream;
+namespace {
+bool tiled_range(int n) { return n > 16384 && n <= 65536; }
+
+int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, char *ws, size_t ws_bytes, hipStream_t s) {
     const int L = ref_block_log2(n);
     const int bs = 1 << L;
     int rc;
@@ -809,8 +808,10 @@ MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz
             else if (P <= 8) rc = launch_resident<MCP_FPS_T8, MCP_FPS_P8, MCP_FPS_J8, false>(b, n, m, L, xyz, temp, idx, s);
             else if (P <= 16) rc = launch_resident<1024, 16, 0, false>(b, n, m, L, xyz, temp, idx, s);
             else {
-                rc = n <= 65536 ? launch_tiled(b, n, m, xyz, temp, idx, s) : MCP_ERR_UNSUPPORTED;
-                if (rc == MCP_ERR_UNSUPPORTED) {  // beyond the tiled kernel's range: plain streaming, any N
+                // the tiled kernel needs scratch for the sorted cloud; without it (or beyond its range): plain streaming, any N
+                rc = (tiled_range(n) && ws && ws_bytes >= tiled_workspace_bytes(b, n)) ? launch_tiled(b, n, m, xyz, temp, idx, ws, s)
+                                                                                      : MCP_ERR_UNSUPPORTED;
+                if (rc == MCP_ERR_UNSUPPORTED) {
                     hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, s, n, m, L, xyz, temp, idx);
                     rc = mcp_launch_status();
                 }
@@ -824,4 +825,23 @@ MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz
     }
     mcp_prof_end(MCP_KERNEL_FPS, s);
     return rc;
+}
+}  // namespace
+
+MCP_EXPORT size_t mcp_fps_workspace_bytes(int b, int n, int m) {
+    (void)m;
+    return (b > 0 && tiled_range(n)) ? tiled_workspace_bytes(b, n) : 0;
+}
+
+MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && temp && idx);
+    if (m <= 0) return MCP_OK;  // sampling_gpu.cu:100
+    return fps_dispatch(b, n, m, xyz, temp, idx, nullptr, 0, (hipStream_t)stream);
+}
+
+MCP_EXPORT int mcp_furthest_point_sampling_ws(int b, int n, int m, const float *xyz, float *temp, int *idx, void *workspace,
+                                              size_t workspace_bytes, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && temp && idx);
+    if (m <= 0) return MCP_OK;
+    return fps_dispatch(b, n, m, xyz, temp, idx, static_cast<char *>(workspace), workspace_bytes, (hipStream_t)stream);
 }

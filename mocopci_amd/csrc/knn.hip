@@ -294,10 +294,9 @@ template <int K, int MODE, int SPLIT>
 int launch_queue(int b, int q, int n, int k, const float *query, const float *ref, int *idx, float *dist, hipStream_t s) {
     const size_t lds = (size_t)KnnLds<K>::WAVE_BYTES * SPLIT;
     auto kern = knn_queue_kernel<K, MODE, SPLIT>;
-    static bool attr_done = false;  // benign race: the attribute is idempotent
-    if (!attr_done) {
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 64), b), dim3(64 * SPLIT), lds, s, q, n, k, query, ref, idx, dist);
     return mcp_launch_status();

@@ -170,10 +170,9 @@ template <int C>
 int launch_cosine(int b, int q, int n, int k, const float *nq, const float *nr, int *idx, float *dist, hipStream_t s) {
     const size_t lds = (size_t)2 * RT * (C + 1) * sizeof(float) + (size_t)WAVES * QS * 64 * sizeof(uint2);
     auto kern = knn_cosine_kernel<C>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 32 * WAVES), b), dim3(64 * WAVES), lds, s, q, n, k, nq, nr, idx, dist);
     return mcp_launch_status();

@@ -211,10 +211,9 @@ template <int IPT>
 int launch_build_cloud(int b, int n, int tiles, const float *xyz, float *sorted_xyz, int *perm, float *boxes, hipStream_t s) {
     auto kern = build_cloud_kernel<IPT>;
     const size_t lds = 512 + sizeof(typename CloudSort<IPT>::Lds);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(b), dim3(BT), lds, s, n, tiles, xyz, sorted_xyz, perm, boxes);
     return mcp_launch_status();
@@ -494,10 +493,9 @@ int launch_pruned_tpl(int b, int q, int n, int tiles, int k, const float *query,
                       const float *boxes, int *idx, float *dist, hipStream_t s) {
     const size_t lds = (size_t)PrunedLds<K>::WAVE_BYTES;
     auto kern = knn_pruned_kernel<K, MODE, SUB, TPL>;
-    static bool attr_done = false;
-    if (!attr_done) {  // lets the CU's whole 160 KB LDS count towards residency (default budget: 64 KB)
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {  // lets the CU's whole 160 KB LDS count towards residency (default budget: 64 KB)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 64 / SUB), b), dim3(64), lds, s, q, n, tiles, k, query, qperm,
                        ref, rperm, boxes, idx, dist);

@@ -643,7 +643,7 @@ class MoCoPCI(nn.Module):
             raise NotImplementedError("inference graph only (train=True needs the backward kernels: SURVEY 8(f) #3)")
         B = xyz1.shape[0]
         xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
-        with torch.no_grad():
+        with torch.no_grad(), ops.backend().cloud_scope():
             self._early = Early(self, xyz.device)
             pcs, feats = self.run_encoder(xyz, self._early)
             return self.run_decoder(pcs, feats, B)

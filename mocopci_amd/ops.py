@@ -11,9 +11,10 @@ that tests and bench.py's cpu_baseline leg can run the SAME graph on the CPU ora
 calling `set_backend(...)`; nothing in this package imports the oracle, and HipBackend has
 no CPU fallback (a CPU tensor raises).
 """
+import contextlib
 import ctypes
 import os
-import weakref
+import threading
 
 import torch
 
@@ -95,7 +96,10 @@ class HipBackend:
         B, N, _ = xyz.shape
         out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
-        _call("mcp_furthest_point_sampling", xyz, B, N, npoint, _lib.fptr(xyz), _lib.fptr(temp), _lib.iptr(out))
+        need = _lib.load().mcp_fps_workspace_bytes(B, N, npoint)  # scratch for the tiled kernel (16384 < N <= 65536), else 0
+        ws = torch.empty((need,), dtype=torch.uint8, device=xyz.device) if need else None
+        _call("mcp_furthest_point_sampling_ws", xyz, B, N, npoint, _lib.fptr(xyz), _lib.fptr(temp), _lib.iptr(out),
+              ws.data_ptr() if need else None, need)
         return out
 
     # clouds at least this large go through the Morton-sorted, box-pruned search (same results)
@@ -103,7 +107,7 @@ class HipBackend:
     PRUNE_MIN_QUERIES = int(os.environ.get("MCP_PRUNE_MIN_QUERIES", "1024"))
 
     def __init__(self):
-        self._clouds = []  # [(weakref(tensor), version, sorted_cloud, stream, built-event)], most recent last
+        self._tls = threading.local()  # .scope: {key: (tensor, sorted cloud, stream, built-event)} while a cloud_scope is open
         self._tile = None
 
     @property
@@ -112,17 +116,22 @@ class HipBackend:
             self._tile = _lib.load().mcp_knn_tile_size()
         return self._tile
 
-    def _sorted_cloud(self, xyz):
-        """Morton order of a cloud: (sorted xyz, perm int32, tile boxes).  Cached per tensor OBJECT (weakref +
-        version counter), because the harness searches the same clouds many times per forward."""
-        cur = torch.cuda.current_stream(xyz.device) if xyz.is_cuda else None
-        for ref, ver, cloud, stream, done in reversed(self._clouds):
-            if ref() is xyz and ver == xyz._version:
-                if cur is not None and stream != cur:  # built on another stream of this forward: order + lifetime
-                    cur.wait_event(done)
-                    for t in cloud:
-                        t.record_stream(cur)
-                return cloud
+    @contextlib.contextmanager
+    def cloud_scope(self):
+        """Within this context the Morton-sorted form of a cloud is built once per tensor and reused by every search on it
+        (the model searches the same clouds many times per forward).  The caller promises not to write into a cloud tensor
+        while the scope is open -- model.forward opens one per call and never does.  Entries hold a strong reference to their
+        tensor, so its storage cannot be recycled under the key; the scope is per thread and dropped on exit.  Outside a scope
+        nothing is cached: every search rebuilds (one extra launch), so buffers a caller reuses between calls are always safe."""
+        outer = getattr(self._tls, "scope", None)
+        self._tls.scope = {} if outer is None else outer
+        try:
+            yield
+        finally:
+            if outer is None:
+                self._tls.scope = None
+
+    def _build_cloud(self, xyz):
         B, N, _ = xyz.shape
         tiles = (N + self.TILE - 1) // self.TILE
         boxes = torch.empty((B, tiles, 6), dtype=torch.float32, device=xyz.device)
@@ -137,13 +146,27 @@ class HipBackend:
             perm = torch.sort(codes, dim=1)[1].int()
             sorted_xyz = self.group_rows(xyz, perm)
             _call("mcp_tile_boxes", xyz, B, N, _lib.fptr(sorted_xyz), _lib.fptr(boxes))
-        cloud = (sorted_xyz, perm, boxes)
-        done = None
-        if cur is not None:
-            done = torch.cuda.Event()
-            done.record(cur)
-        self._clouds = [e for e in self._clouds if e[0]() is not None][-7:]
-        self._clouds.append((weakref.ref(xyz), xyz._version, cloud, cur, done))
+        return sorted_xyz, perm, boxes
+
+    def _sorted_cloud(self, xyz):
+        """Morton order of a cloud: (sorted xyz, perm int32, tile boxes); cached only inside a cloud_scope."""
+        scope = getattr(self._tls, "scope", None)
+        if scope is None:
+            return self._build_cloud(xyz)
+        cur = torch.cuda.current_stream(xyz.device)
+        key = (xyz.data_ptr(), tuple(xyz.shape), xyz.device.index)
+        hit = scope.get(key)
+        if hit is not None:
+            _, cloud, stream, done = hit
+            if stream != cur:  # built on another stream of this forward: order + lifetime
+                cur.wait_event(done)
+                for t in cloud:
+                    t.record_stream(cur)
+            return cloud
+        cloud = self._build_cloud(xyz)
+        done = torch.cuda.Event()
+        done.record(cur)
+        scope[key] = (xyz, cloud, cur, done)
         return cloud
 
     def knn(self, query, ref, k, mode=MCP_DIST_EXPANSION, return_dist=False):
@@ -156,7 +179,8 @@ class HipBackend:
         if N >= self.PRUNE_MIN_REFS and Q >= self.PRUNE_MIN_QUERIES and k <= 32 and N <= 65536:
             _lib.fptr(query), _lib.fptr(ref)  # validate before building the sorted clouds
             rs, rperm, boxes = self._sorted_cloud(ref)
-            qs, qperm, _ = self._sorted_cloud(query)
+            same = query.data_ptr() == ref.data_ptr() and query.shape == ref.shape
+            qs, qperm, _ = (rs, rperm, boxes) if same else self._sorted_cloud(query)
             _call("mcp_knn_pruned", query, B, Q, N, k, mode, _lib.fptr(qs), _lib.iptr(qperm), _lib.fptr(rs), _lib.iptr(rperm),
                   _lib.fptr(boxes), _lib.iptr(idx), _lib.fptr(dist) if return_dist else None)
         else:
@@ -222,7 +246,9 @@ class HipBackend:
         """UpsampleFlow.forward (mocopci.py:1485-1502): dense (B,N,3), sparse (B,S,3), feat (B,S,C) -> (B,N,C)."""
         B, N, _ = dense.shape
         S, C = feat.shape[1], feat.shape[2]
-        if S >= self.PRUNE_MIN_REFS and N >= self.PRUNE_MIN_QUERIES:  # large levels: spatially pruned 3-NN search
+        # large levels: spatially pruned 3-NN search.  The same two-step route carries the gradient w.r.t. feat (the fused
+        # small-level kernel below has no autograd node), so it is also taken whenever a gradient is wanted.
+        if (S >= self.PRUNE_MIN_REFS and N >= self.PRUNE_MIN_QUERIES) or (feat.requires_grad and torch.is_grad_enabled()):
             idx3, w3 = self.interp3_search(dense, sparse)
             return self.interp3_apply(feat, idx3, w3)
         idx3 = torch.empty((B, N, 3), dtype=torch.int32, device=dense.device)

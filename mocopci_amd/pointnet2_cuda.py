@@ -16,7 +16,12 @@ def _call(name, ref_tensor, *args):
 
 
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
-    return _call("mcp_furthest_point_sampling", points, b, n, m, _lib.fptr(points), _lib.fptr(temp), _lib.iptr(idx))
+    # the library never allocates: sizes that can use scratch (16384 < N <= 65536) get it from torch's caching allocator
+    need = _lib.load().mcp_fps_workspace_bytes(b, n, m)
+    if need == 0:
+        return _call("mcp_furthest_point_sampling", points, b, n, m, _lib.fptr(points), _lib.fptr(temp), _lib.iptr(idx))
+    ws = torch.empty((need,), dtype=torch.uint8, device=points.device)
+    return _call("mcp_furthest_point_sampling_ws", points, b, n, m, _lib.fptr(points), _lib.fptr(temp), _lib.iptr(idx), ws.data_ptr(), need)
 
 
 def gather_points_wrapper(b, c, n, npoints, points, idx, out):

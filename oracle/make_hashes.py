@@ -34,6 +34,11 @@ def main():
     x = big_cloud(16384)
     out["knn16_direct_16384"] = h(orc.knn(x, x, 16, mode=1))
     out["ball_query_16384_r1_16"] = h(orc.ball_query(1.0, 16, x, x[:, :2048].contiguous()))
+    # BASELINE configs[4] at its full shape (synthetic N=65536 dense scan, batch 8): FPS 65536 -> 2048 for all 8 clouds, and the
+    # K=32 self search for a 4096-query slice of cloud 0 (the GPU test runs the whole Q=65536 search and compares the slice)
+    x = big_cloud(65536, seed=5, batch=8)
+    out["fps_c5_8x65536_2048"] = h(orc.furthest_point_sample(x, 2048))
+    out["knn32_c5_65536_rows_30000_34096"] = h(orc.knn(x[:1, 30000:34096].contiguous(), x[:1], 32))
     json.dump(out, open(OUT, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

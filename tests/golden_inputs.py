@@ -24,6 +24,13 @@ def layer_inputs():
     }
 
 
+def module_inputs():
+    """Inputs of the QueryAndGroup / GroupAll fixtures (pointnet2_modules.npz): a 1024-point cloud, 64 centres taken from it
+    (so some balls hold only their centre and some overflow nsample), 16-channel features in the reference's (B,C,N) layout."""
+    xyz = layer_inputs()["xyz_big"]
+    return {"xyz": xyz, "new_xyz": xyz[:, ::16].contiguous(), "features": _r(22, 1, 16, 1024)}
+
+
 def big_cloud(n, seed=1, batch=1):
     """Seeded LiDAR-like box cloud with 5 % duplicated points (full-size hash pins)."""
     g = torch.Generator().manual_seed(1000 * seed + n)

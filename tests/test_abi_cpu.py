@@ -12,7 +12,7 @@ def header_functions():
     src = open(os.path.join(ROOT, "include", "mocopci_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"(?:int|const char \*)\s*(mcp_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(?:int|size_t|const char \*)\s*(mcp_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return out
@@ -40,3 +40,13 @@ def test_argument_validation_needs_no_gpu():
     lib = _lib.load()
     assert lib.mcp_furthest_point_sampling(0, 0, 0, None, None, None, None) == 10001
     assert lib.mcp_knn(1, 1, 1, 64, 0, None, None, None, None, None) == 10001
+    assert lib.mcp_furthest_point_sampling_ws(1, 0, 1, None, None, None, None, 0, None) == 10001
+
+
+def test_fps_workspace_query():
+    """Only the tiled kernel's range (16384 < N <= 65536) uses scratch: 20 bytes per point of the padded cloud."""
+    lib = _lib.load()
+    assert lib.mcp_fps_workspace_bytes(8, 8192, 2048) == 0 and lib.mcp_fps_workspace_bytes(8, 16384, 2048) == 0
+    assert lib.mcp_fps_workspace_bytes(8, 65536, 2048) == 8 * 65536 * 20
+    assert lib.mcp_fps_workspace_bytes(2, 20000, 16) == 2 * 20032 * 20
+    assert lib.mcp_fps_workspace_bytes(1, 65537, 16) == 0

@@ -26,9 +26,9 @@ def test_hip_emd_known_answer_and_oracle_parity():
     cost = emd.earth_mover_distance(p1, p2, transpose=False)
     assert torch.allclose(cost.cpu(), torch.full((3,), 0.71), atol=1e-5)
     g = torch.Generator().manual_seed(3)
-    for n, m in ((512, 512), (1000, 500), (300, 900), (2048, 2048)):
-        x = torch.rand(2, n, 3, generator=g) * 4
-        y = torch.rand(2, m, 3, generator=g) * 4
+    for n, m, b in ((512, 512, 2), (1000, 500, 2), (300, 900, 2), (2048, 2048, 2), (4096, 4096, 1)):
+        x = torch.rand(b, n, 3, generator=g) * 4
+        y = torch.rand(b, m, 3, generator=g) * 4
         want, wmatch = orc.earth_mover_distance(x, y, return_match=True)
         got = emd.earth_mover_distance(x.to(dev), y.to(dev), transpose=False).cpu()
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)                    # north_star: EMD within 1e-5 relative
@@ -52,3 +52,16 @@ def test_hip_emd_full_size_properties():
     c0 = float(emd.earth_mover_distance(x, x, transpose=False))
     c1 = float(emd.earth_mover_distance(x, (x + 0.05).contiguous(), transpose=False))
     assert c0 / 8192 < 1e-3 and c1 > c0 and abs(c1 / 8192 - 3 * 0.05 ** 2) < 5e-3
+
+
+@pytest.mark.gpu
+def test_hip_emd_baseline_point_count_matches_oracle():
+    """N=8192 (BASELINE configs[1]'s point count), one LiDAR-like pair: cost within the north-star 1e-5 relative of the
+    oracle (about 2e9 exponentials on the host: ~20 s)."""
+    from mocopci_amd import emd
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(1, 8192, 3, generator=g) * torch.tensor([80.0, 80.0, 6.0])
+    y = (x[:, torch.randperm(8192, generator=g)] + 0.05 * torch.randn(1, 8192, 3, generator=g)).contiguous()
+    want = orc.earth_mover_distance(x, y)
+    got = emd.earth_mover_distance(x.to("cuda:0"), y.to("cuda:0"), transpose=False).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)

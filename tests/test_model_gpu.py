@@ -60,3 +60,50 @@ def test_forward_full_size_matches_the_oracle_backend():
         cg = float(be.chamfer(g.contiguous(), gt[j]))
         cw = float(be.chamfer(w.to("cuda:0").contiguous(), gt[j]))
         assert abs(cg - cw) <= 1e-5 * abs(cw), (j, cg, cw)
+
+
+def test_config4_model_runs_at_full_batch_and_matches_the_oracle_backend():
+    """BASELINE configs[3]: NuScenes-like N=16384 scan (x,y in +-50, z in [-5,3]), batch 8, as a MODEL run.  The full batch
+    must be finite and bit-reproducible; sequence 0 is compared with the same graph on the CPU oracle backend (exact sampled
+    pyramid, frames within the displacement budgets of harness_checks); per-sample independence: sequence 0 of the batch-8
+    run equals the batch-1 run bit for bit (every layer is per-sample in eval mode)."""
+    import numpy as np
+    from mocopci_amd import synth
+    from oracle.backend import OracleBackend
+    kw = dict(extent=50.0, zlo=-5.0, zhi=3.0)
+    net = hc.build_model("cuda:0")
+    x1, x2, gt = synth.make_batch(4, 8, 16384, device="cuda:0", **kw)
+    a = net(x1, x2)
+    b = net(x1, x2)
+    for u, v in zip(a, b):
+        assert u.shape == (8, 16384, 3) and torch.isfinite(u).all() and torch.equal(u, v)
+    one = net(x1[:1].contiguous(), x2[:1].contiguous())
+    for u, v in zip(a, one):
+        assert torch.equal(u[:1], v)
+    cpu_net = hc.build_model("cpu")
+    prev = ops.set_backend(OracleBackend())
+    try:
+        want = cpu_net(x1[:1].cpu(), x2[:1].cpu())
+        pcs_w, _ = cpu_net.run_encoder(x1[:1].cpu().transpose(1, 2).contiguous())
+    finally:
+        ops.set_backend(prev)
+    pcs_g, _ = net.run_encoder(x1[:1].transpose(1, 2).contiguous())
+    for lvl in range(1, 5):
+        assert torch.equal(pcs_g[lvl].cpu(), pcs_w[lvl]), lvl
+    for j in range(3):
+        elem, pts, worst, mse = hc.frame_deviation(one[j].cpu().numpy(), want[j].numpy())
+        line = f"config4 frame {j}: coords off {elem:.4%}, points moved {pts:.4%}, worst {worst:.3g} x spread, mse {mse:.3g} x spread^2"
+        print(line)
+        assert elem <= 0.02 and pts <= hc.POINT_BUDGET and worst <= hc.MAX_DISP_BUDGET and mse <= hc.MSE_BUDGET, line
+
+
+def test_forward_under_inference_mode():
+    """inference tensors have no version counter; the forward must not depend on one (N=8192 takes the pruned search)."""
+    from mocopci_amd import synth
+    net = hc.build_model("cuda:0")
+    x1, x2, _ = synth.make_batch(2, 1, 8192, device="cuda:0")
+    want = net(x1, x2)
+    with torch.inference_mode():
+        got = net(x1.clone(), x2.clone())
+    for u, v in zip(got, want):
+        assert torch.equal(u, v)

@@ -417,3 +417,120 @@ def test_ptblock_attention_matches_unfused_oracle(n):
     be = ops.backend()
     got = be.ptblock_attention(*[t.to(DEV) for t in (xyz, q, k, v, idx)], be.ptblock_pack(*[w.to(DEV) for w in ws])).cpu()
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
+def test_grouping_modules_match_reference_classes(golden_dir):
+    """QueryAndGroup / GroupAll of mocopci_amd.pointnet2_utils on the HIP kernels against the outputs of the REFERENCE'S own
+    classes (pointnet2/pointnet2_utils.py:231-290; fixture from oracle/make_golden.py): bit-exact -- ball query indices, two
+    gathers and one exact subtraction."""
+    import os
+    from tests import golden_inputs as gi
+    g = np.load(os.path.join(golden_dir, "pointnet2_modules.npz"))
+    mi = {k: v.to(DEV) for k, v in gi.module_inputs().items()}
+    for r, ns, key in ((0.5, 16, "qg_r0.5_n16"), (2.0, 8, "qg_r2.0_n8")):
+        got = pu.QueryAndGroup(r, ns)(mi["xyz"], mi["new_xyz"], mi["features"])
+        assert got.shape == g[key].shape and np.array_equal(got.cpu().numpy(), g[key])
+    assert np.array_equal(pu.QueryAndGroup(1.0, 8)(mi["xyz"], mi["new_xyz"], None).cpu().numpy(), g["qg_xyz_only"])
+    assert np.array_equal(pu.QueryAndGroup(1.0, 8, use_xyz=False)(mi["xyz"], mi["new_xyz"], mi["features"]).cpu().numpy(), g["qg_no_xyz"])
+    assert np.array_equal(pu.GroupAll()(mi["xyz"], None, mi["features"]).cpu().numpy(), g["group_all"])
+    with pytest.raises(AssertionError):
+        pu.QueryAndGroup(1.0, 8, use_xyz=False)(mi["xyz"], mi["new_xyz"], None)
+
+
+def test_models_common_aliases_match_oracle():
+    """The `models.common` names models/layers.py:15,35,37,62,64,162,170 imports (the reference does not ship that module):
+    fps, gather_points, ball_query, three_nn, three_interpolate, group_points, bound by compat.install()."""
+    import sys
+    from mocopci_amd import compat
+    saved = {k: sys.modules.get(k) for k in ("pointnet2_cuda", "pointnet2.pointnet2_utils", "models.pointnet2.pointnet2_utils", "models.common")}
+    try:
+        sys.modules.pop("models.common", None)
+        compat.install()
+        common = sys.modules["models.common"]
+        xyz = cloud(41, 2, 1500)
+        feats = torch.randn(2, 12, 1500, generator=torch.Generator().manual_seed(5))
+        x, f = xyz.to(DEV), feats.to(DEV)
+        sel = common.fps(x, 200)
+        want_sel = orc.furthest_point_sample(xyz, 200)
+        assert torch.equal(sel.cpu(), want_sel)
+        new_f = common.gather_points(f, sel)
+        assert torch.equal(new_f.cpu(), orc.gather_operation(feats, want_sel))
+        new_xyz = common.gather_points(x.transpose(1, 2).contiguous(), sel).transpose(1, 2).contiguous()
+        bq = common.ball_query(1.5, 12, x, new_xyz)
+        want_bq = orc.ball_query(1.5, 12, xyz, new_xyz.cpu())
+        assert torch.equal(bq.cpu(), want_bq)
+        assert torch.equal(common.group_points(f, bq).cpu(), orc.grouping_operation(feats, want_bq))
+        d, i3 = common.three_nn(x, new_xyz)
+        wd, wi = orc.three_nn(xyz, new_xyz.cpu())
+        assert torch.equal(i3.cpu(), wi) and torch.equal(d.cpu(), wd)
+        w = torch.softmax(-d, dim=-1).contiguous()
+        assert torch.equal(common.three_interpolate(new_f, i3, w).cpu(), orc.three_interpolate(new_f.cpu(), wi, w.cpu()))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_config5_full_shape_pins():
+    """BASELINE configs[4] at its full shape -- synthetic N=65536 dense scan, batch 8 (the FPS + KNN roofline run): FPS
+    65536 -> 2048 of all eight clouds (tiled kernel, caller-provided workspace) against the oracle's SHA pin; the K=32
+    self search with Q = N = 65536 (pruned kernel): a 4096-query slice against the oracle's pin, the same slice against
+    the exhaustive kernel, and -- for every query of every cloud -- ascending distances with the query itself first."""
+    import hashlib, json, os
+    from tests.golden_inputs import big_cloud
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hashes.json")))
+    h = lambda t: hashlib.sha256(t.cpu().contiguous().numpy().tobytes()).hexdigest()
+    be = ops.backend()
+    x = big_cloud(65536, seed=5, batch=8).to(DEV)
+    assert _lib.load().mcp_fps_workspace_bytes(8, 65536, 2048) == 8 * 65536 * 20
+    sel = pu.furthest_point_sample(x, 2048)
+    assert h(sel) == pins["fps_c5_8x65536_2048"]
+    # the reference wrapper's exact argument list (no workspace) takes the streaming kernel: same indices (two clouds: it is slow)
+    t = torch.full((2, 65536), 1e10, device=DEV)
+    o = torch.zeros((2, 2048), dtype=torch.int32, device=DEV)
+    _lib.check(_lib.load().mcp_furthest_point_sampling(2, 65536, 2048, x.data_ptr(), t.data_ptr(), o.data_ptr(), _lib.stream()))
+    assert torch.equal(o, sel[:2])
+    idx, dist = be.knn(x, x, 32, return_dist=True)
+    assert h(idx[:1, 30000:34096]) == pins["knn32_c5_65536_rows_30000_34096"]
+    assert torch.equal(idx[:1, 30000:34096], be.knn_bruteforce(x[:1, 30000:34096].contiguous(), x[:1], 32))
+    assert bool((dist[..., 1:] >= dist[..., :-1]).all())
+    # a point's nearest neighbour is itself or an exact duplicate of it with a lower index (5 % of the points are duplicates)
+    first = be.group_rows(x, idx[..., 0].contiguous())
+    assert torch.equal(first, x) and bool((idx[..., 0] <= torch.arange(65536, device=DEV, dtype=torch.int32)).all())
+
+
+@pytest.mark.parametrize("n,s,c", [(300, 100, 7), (1500, 700, 64), (4096, 2048, 16)])
+def test_interp3_gradient_flows_at_every_size(n, s, c):
+    """UpsampleFlow (mocopci.py:1485-1502) is differentiable w.r.t. the sparse features whichever kernel route the sizes
+    select (fused small-level kernel / pruned search + blend): gradient against torch autograd of the same blend."""
+    dense, sparse = cloud(n, 2, n).to(DEV), cloud(s + 1, 2, s).to(DEV)
+    feat = torch.randn(2, s, c, device=DEV, generator=torch.Generator(device=DEV).manual_seed(n), requires_grad=True)
+    be = ops.backend()
+    out = be.interp3(dense, sparse, feat)
+    assert out.requires_grad
+    g = torch.randn_like(out)
+    (grad,) = torch.autograd.grad(out, feat, g)
+    with torch.no_grad():
+        assert torch.equal(out, be.interp3(dense, sparse, feat.detach()))  # same values as the inference route
+        idx3, w3 = be.interp3_search(dense, sparse)
+    f2 = feat.detach().clone().requires_grad_(True)
+    rows = torch.gather(f2.unsqueeze(1).expand(-1, n, -1, -1), 2, idx3.long().unsqueeze(-1).expand(-1, -1, -1, c))
+    ref = (rows * w3.unsqueeze(-1)).sum(2)
+    (want,) = torch.autograd.grad(ref, f2, g)
+    torch.testing.assert_close(grad, want, rtol=1e-5, atol=1e-5)
+
+
+def test_search_on_a_reused_buffer_sees_the_new_contents():
+    """a buffer written through the library's raw-pointer entry points and then searched as a cloud must never be
+    answered from a stale sorted copy.  Outside model.forward's cloud_scope nothing is cached."""
+    a, b = cloud(71, 1, 4096), cloud(72, 1, 4096)
+    buf = a.to(DEV).clone()
+    be = ops.backend()
+    assert torch.equal(be.knn(buf, buf, 16).cpu(), orc.knn(a, a, 16))
+    src = b.to(DEV)
+    ar = torch.arange(4096, dtype=torch.int32, device=DEV).unsqueeze(0).contiguous()
+    ops._call("mcp_group_rows", src, 1, 4096, 3, 4096, src.data_ptr(), ar.data_ptr(), buf.data_ptr())  # raw write, no version bump
+    assert torch.equal(buf.cpu(), b)
+    assert torch.equal(be.knn(buf, buf, 16).cpu(), orc.knn(b, b, 16))

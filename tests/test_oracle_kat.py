@@ -88,3 +88,20 @@ def test_chamfer_matches_definition():
     x = torch.tensor([[[0., 0, 0], [1, 0, 0]]])
     y = torch.tensor([[[0., 0, 0]]])
     assert abs(orc.chamfer(x, y) - (0.5 + 0.0)) < 1e-12  # mean_x min = (0+1)/2, mean_y min = 0
+
+
+def test_oracle_grouping_modules_against_reference_classes(golden_dir):
+    """QueryAndGroup / GroupAll (pointnet2/pointnet2_utils.py:231-290): the fixture holds the outputs of the REFERENCE'S classes;
+    here the same composition is rebuilt from the oracle's ball_query / grouping_operation and must agree exactly."""
+    import os
+    from tests import golden_inputs as gi
+    g = np.load(os.path.join(golden_dir, "pointnet2_modules.npz"))
+    mi = gi.module_inputs()
+    for r, ns, key in ((0.5, 16, "qg_r0.5_n16"), (2.0, 8, "qg_r2.0_n8")):
+        idx = orc.ball_query(r, ns, mi["xyz"], mi["new_xyz"])
+        gx = orc.grouping_operation(mi["xyz"].transpose(1, 2).contiguous(), idx) - mi["new_xyz"].transpose(1, 2).unsqueeze(-1)
+        want = torch.cat([gx, orc.grouping_operation(mi["features"], idx)], dim=1)
+        assert np.array_equal(want.numpy(), g[key])
+    # the centres are cloud points: every ball holds at least its centre, and r=0.5 leaves some balls short of nsample (padding)
+    idx = orc.ball_query(0.5, 16, mi["xyz"], mi["new_xyz"])
+    assert bool((idx[0, :, 1:] == idx[0, :, :1]).all(dim=1).any()) or bool((idx[0, :, -1] == idx[0, :, 0]).any())
