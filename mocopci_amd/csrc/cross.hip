@@ -17,6 +17,9 @@
 //     (weights pre-permuted in LDS, as in fusion.hip), bias as the initial accumulator;
 //   * the max over neighbours is a DPP row reduction + one cross-row shuffle per register.
 // HBM/L2 traffic is the compulsory gather (32 rows of D floats per point) + D floats out.
+// D = 256 (cross3, pointconv_util.py:783-791): the 256 KB weight image does not fit the CU's 160 KB of LDS, so the output
+// channels are split over blockIdx.y into two halves of four 32-channel tiles (128 KB of weights resident per workgroup);
+// each half rebuilds x0 from its own gather (an L2-resident 32 KB per point) rather than exchanging it.
 #include "common.h"
 
 namespace {
@@ -117,22 +120,27 @@ __global__ __launch_bounds__(256) void cross_pack_kernel(const float *__restrict
 // The kernel is latency-bound (one point in flight per wave through idx -> gathers -> MFMA -> reduce), so residency
 // matters more than unrolling: the output-tile loop is kept rolled and registers are capped for 3 (D=64) / 2 (D=128)
 // waves per SIMD.
-template <int D>
-__global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : 2)) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
+template <int D, int SPLIT>
+__global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : D == 128 ? 2 : 1)) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
                                                            const float *__restrict__ xyz2, const float *__restrict__ points1,
                                                            const float *__restrict__ points2, const int *__restrict__ idx,
                                                            const float *__restrict__ packed, float *__restrict__ out) {
     using L = CrossLds<D>;
     constexpr int T = L::T, KQ = T * 4;  // k-quads per output tile
+    constexpr int TO = T / SPLIT;        // output tiles of this workgroup: TO * split .. TO * split + TO - 1
+    constexpr int WH = L::W_FLOATS / SPLIT, SMALL = L::POS_FLOATS + L::B_FLOATS;  // LDS image: [this half of W | pos | bias]
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    static_assert(L::FLOATS % 4 == 0, "LDS image is copied as float4");
-    for (int e = tid; e < L::FLOATS / 4; e += 64 * WAVES)
-        reinterpret_cast<float4 *>(lds)[e] = reinterpret_cast<const float4 *>(packed)[e];
+    const int tid = threadIdx.x, split = blockIdx.y;
+    static_assert(WH % 4 == 0 && SMALL % 4 == 0, "LDS image is copied as float4");
+    for (int e = tid; e < WH / 4; e += 64 * WAVES)
+        reinterpret_cast<float4 *>(lds)[e] = reinterpret_cast<const float4 *>(packed + L::OFF_W + (size_t)split * WH)[e];
+    for (int e = tid; e < SMALL / 4; e += 64 * WAVES)
+        reinterpret_cast<float4 *>(lds + WH)[e] = reinterpret_cast<const float4 *>(packed + L::OFF_POS)[e];
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
-    const float4 *wq = reinterpret_cast<const float4 *>(lds + L::OFF_W);
+    const float4 *wq = reinterpret_cast<const float4 *>(lds);
+    const float *lpos = lds + WH, *lbias = lds + WH + L::POS_FLOATS;
 
     // Software pipeline over the wave's points: the neighbour index of point i+2 and the gathered rows of point i+1 are
     // in flight while the D x D layer of point i runs on the MFMA pipe (the row registers are free again once layer 1
@@ -176,8 +184,8 @@ __global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : 2)) void cross_kernel(lo
                 const float4 a = PRE_A ? ra[t][g] : row1[(32 * t + 8 * g + 4 * h) >> 2];
                 acc[4 * g + 0] = a.x; acc[4 * g + 1] = a.y; acc[4 * g + 2] = a.z; acc[4 * g + 3] = a.w;
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L::OFF_POS + (t * 2 + 0) * 64 + lane], in0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L::OFF_POS + (t * 2 + 1) * 64 + lane], in1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lpos[(t * 2 + 0) * 64 + lane], in0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lpos[(t * 2 + 1) * 64 + lane], in1, acc, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 acc[4 * g + 0] = leaky(acc[4 * g + 0] + rg[t][g].x);
@@ -192,13 +200,14 @@ __global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : 2)) void cross_kernel(lo
             if (pn + stride < total) idn = idx[(pn + stride) * KNB + col];
         }
 #pragma unroll 1
-        for (int t = 0; t < T; ++t) {
+        for (int tl = 0; tl < TO; ++tl) {
+            const int t = TO * split + tl;
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = lds[L::OFF_B + (t * 2 + h) * 16 + r];
+            for (int r = 0; r < 16; ++r) acc[r] = lbias[(t * 2 + h) * 16 + r];
 #pragma unroll
             for (int q4 = 0; q4 < KQ; ++q4) {
-                const float4 w = wq[(t * KQ + q4) * 64 + lane];
+                const float4 w = wq[(tl * KQ + q4) * 64 + lane];
                 const int tin = q4 >> 2, r0 = (q4 & 3) * 4;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x0[tin][r0 + 0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x0[tin][r0 + 1], acc, 0, 0, 0);
@@ -211,11 +220,12 @@ __global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : 2)) void cross_kernel(lo
     }
 }
 
-template <int D>
+template <int D, int SPLIT>
 int launch_cross(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
                  const int *idx, const float *packed, float *out, hipStream_t s) {
-    const size_t lds = CrossLds<D>::FLOATS * sizeof(float);
-    auto kern = cross_kernel<D>;
+    using L = CrossLds<D>;
+    const size_t lds = (L::W_FLOATS / SPLIT + L::POS_FLOATS + L::B_FLOATS) * sizeof(float);
+    auto kern = cross_kernel<D, SPLIT>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -224,38 +234,40 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
     const long long want = (total + WAVES * 8 - 1) / (WAVES * 8);
     // persistent-style grid = exactly the resident slots (256 CUs x 3 or 2 workgroups, see __launch_bounds__): a larger
     // grid leaves a partly filled second round of workgroups
-    const unsigned grid = (unsigned)max(1LL, min(want, (long long)(D == 64 ? 768 : 512)));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out);
+    const unsigned grid = (unsigned)max(1LL, min(want, (long long)(D == 64 ? 768 : D == 128 ? 512 : 256 / SPLIT)));
+    hipLaunchKernelGGL(kern, dim3(grid, SPLIT), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out);
     return mcp_launch_status();
 }
 
 }  // namespace
 
 MCP_EXPORT int mcp_cross_packed_floats(int d) {
-    return d == 64 ? CrossLds<64>::FLOATS : d == 128 ? CrossLds<128>::FLOATS : 0;
+    return d == 64 ? CrossLds<64>::FLOATS : d == 128 ? CrossLds<128>::FLOATS : d == 256 ? CrossLds<256>::FLOATS : 0;
 }
 
 MCP_EXPORT int mcp_cross_pack(int d, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, float *packed,
                               mcp_stream_t stream) {
     MCP_CHECK_ARGS(wpos && bpos && wmlp && bmlp && packed);
-    if (d != 64 && d != 128) return MCP_ERR_UNSUPPORTED;
+    if (d != 64 && d != 128 && d != 256) return MCP_ERR_UNSUPPORTED;
     if (((uintptr_t)packed) & 15) return MCP_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (d == 64) hipLaunchKernelGGL(cross_pack_kernel<64>, dim3(16), dim3(256), 0, s, wpos, bpos, wmlp, bmlp, packed);
-    else hipLaunchKernelGGL(cross_pack_kernel<128>, dim3(64), dim3(256), 0, s, wpos, bpos, wmlp, bmlp, packed);
+    else if (d == 128) hipLaunchKernelGGL(cross_pack_kernel<128>, dim3(64), dim3(256), 0, s, wpos, bpos, wmlp, bmlp, packed);
+    else hipLaunchKernelGGL(cross_pack_kernel<256>, dim3(256), dim3(256), 0, s, wpos, bpos, wmlp, bmlp, packed);
     return mcp_launch_status();
 }
 
 MCP_EXPORT int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
                                 const float *points2, const int *idx, const float *packed, float *out, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && packed && out);
-    if (k != KNB || (d != 64 && d != 128)) return MCP_ERR_UNSUPPORTED;
+    if (k != KNB || (d != 64 && d != 128 && d != 256)) return MCP_ERR_UNSUPPORTED;
     if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)out) | ((uintptr_t)packed)) & 15) return MCP_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)b * n1;
     mcp_prof_begin(MCP_KERNEL_CROSS, s);
-    const int rc = d == 64 ? launch_cross<64>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s)
-                           : launch_cross<128>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s);
+    const int rc = d == 64    ? launch_cross<64, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s)
+                   : d == 128 ? launch_cross<128, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s)
+                              : launch_cross<256, 2>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s);
     mcp_prof_end(MCP_KERNEL_CROSS, s);
     return rc;
 }

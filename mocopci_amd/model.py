@@ -277,24 +277,14 @@ class MoCoPCI(nn.Module):
         else:
             idx_p = be.knn(xyz1, xyz2, 16)
         idx = torch.cat([idx_c, idx_p], dim=-1)                           # (B,N1,32)
-        D = points1.shape[-1]
-        if len(mlp) == 1 and D in (64, 128) and points2.shape[-1] == D:
-            conv = mlp[0] + ".composed_module.0"
-            P = self._params()
-            key = ("cross_pack", be.name, pos, conv)
-            if key not in P:  # the layer's weights in the kernel's operand layout, built once
-                P[key] = be.cross_pack(self.W(pos), self.Bv(pos), self.W(conv), self.Bv(conv))
-            return be.cross_volume(xyz1, xyz2, points1.contiguous(), points2.contiguous(), idx, P[key])
-        # Unfused path (D = 256 at level 3).  pos(xyz2[idx] - xyz1) is linear, so it is applied per POINT, not per
-        # (point, neighbour): a2 = points2 + W xyz2 is gathered, a1 = points1 - W xyz1 + b is broadcast.
-        wpos = self.W(pos)
-        a2 = points2 + F.linear(xyz2, wpos)
-        a1 = points1 - F.linear(xyz1, wpos, None if self.Bv(pos) is None else -self.Bv(pos))
-        x = be.group_rows_add_leaky(a2.contiguous(), idx, a1.contiguous(), 0.1)   # leaky(a2[idx] + a1): (B,N1,32,D)
-        for name in mlp[:-1]:
-            x = leaky(self.lin(x, name + ".composed_module.0"))
-        # LeakyReLU is monotone: the max over the 32 neighbours commutes with it
-        return leaky(self.lin(x, mlp[-1] + ".composed_module.0").max(dim=2)[0])
+        # every cross() MoCoPCI builds has one D -> D mlp layer with D in {64, 128, 256} (pointconv_util.py:735-748)
+        assert len(mlp) == 1 and points2.shape[-1] == points1.shape[-1]
+        conv = mlp[0] + ".composed_module.0"
+        P = self._params()
+        key = ("cross_pack", be.name, pos, conv)
+        if key not in P:  # the layer's weights in the kernel's operand layout, built once
+            P[key] = be.cross_pack(self.W(pos), self.Bv(pos), self.W(conv), self.Bv(conv))
+        return be.cross_volume(xyz1, xyz2, points1.contiguous(), points2.contiguous(), idx, P[key])
 
     def interp(self, dense, sparse, feat, cache=None, key=None):
         """UpsampleFlow (mocopci.py:1485-1502) with search reuse on a keyed (dense, sparse) pair."""

@@ -272,14 +272,14 @@ class HipBackend:
         lib = _lib.load()
         n = lib.mcp_cross_packed_floats(D)
         if n == 0:
-            raise RuntimeError(f"cross_volume supports D in (64, 128), got {D}")
+            raise RuntimeError(f"cross_volume supports D in (64, 128, 256), got {D}")
         packed = torch.empty((n,), dtype=torch.float32, device=wmlp.device)
         _call("mcp_cross_pack", wmlp, D, _lib.fptr(wpos.contiguous()), _lib.fptr(bpos.contiguous()), _lib.fptr(wmlp.contiguous()),
               _lib.fptr(bmlp.contiguous()), _lib.fptr(packed))
         return packed
 
     def cross_volume(self, xyz1, xyz2, points1, points2, idx, packed):
-        """cross() after its neighbour searches (pointconv_util.py:750-781): -> (B,N1,D); D in {64,128};
+        """cross() after its neighbour searches (pointconv_util.py:750-781): -> (B,N1,D); D in {64,128,256};
         packed = cross_pack(wpos, bpos, wmlp, bmlp)."""
         B, N1, D = points1.shape
         N2 = points2.shape[1]

@@ -254,7 +254,7 @@ def test_fusion_mlp_matches_unfused_oracle():
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("d,n1,n2", [(64, 2048, 2048), (128, 512, 512), (64, 300, 777)])
+@pytest.mark.parametrize("d,n1,n2", [(64, 2048, 2048), (128, 512, 512), (64, 300, 777), (256, 256, 256), (256, 37, 500)])
 def test_cross_volume_matches_unfused_oracle(d, n1, n2):
     from oracle.backend import OracleBackend
     g = torch.Generator().manual_seed(d + n1)
