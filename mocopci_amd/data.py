@@ -9,6 +9,10 @@ data/no_norm_datasets.py:8-91:
     duplicate points in the inputs come from;
   * __getitem__ -> (input: num_frames x (N,3) tensors, gt: (interval-1) x (N,3) tensors).
 np.random is used in the reference's call order, so a seeded run reproduces the reference's sample.
+
+GPU-side resampling (NLDriveDataset(device=...)): the raw scan is uploaded once, whole, and the row selection runs on the GPU
+(mcp_group_rows); the index list still comes from np.random in the reference's call order (O(N) host work, no point data
+touched on the host), so the sample is bit-identical to the host path's and the duplicated rows are exact duplicates.
 """
 import os
 
@@ -31,9 +35,20 @@ def resample_indices(num, num_points):
     return np.concatenate((np.arange(num), np.random.choice(num, num_points - num, replace=True)), axis=-1)
 
 
+def resample_on_device(raw, pick, device):
+    """raw (n,3) float32 numpy scan, pick (num_points,) indices -> (num_points,3) float32 tensor on `device`, gathered there."""
+    from . import ops
+    pts = torch.from_numpy(np.ascontiguousarray(raw, dtype=np.float32)).to(device, non_blocking=True).unsqueeze(0)
+    idx = torch.from_numpy(np.ascontiguousarray(pick, dtype=np.int32)).to(device, non_blocking=True).unsqueeze(0)
+    return ops.backend().group_rows(pts, idx)[0]
+
+
 class NLDriveDataset(Dataset):
-    def __init__(self, data_root, scene_list, num_points=8192, interval=4, num_frames=4):
+    def __init__(self, data_root, scene_list, num_points=8192, interval=4, num_frames=4, device=None):
+        """device: None = the reference's host path (numpy fancy indexing); a CUDA device = GPU-side resampling (use with
+        num_workers=0: the frames come back as tensors of that device)."""
         super().__init__()
+        self.device = device
         self.data_root, self.scene_list = data_root, scene_list
         self.num_points, self.interval, self.num_frames = num_points, interval, num_frames
         with open(scene_list, "r") as fh:
@@ -56,6 +71,9 @@ class NLDriveDataset(Dataset):
             raw = read_frame(os.path.join(self.data_root, names[3 + (i + 1) * gt_intv]))
             gts.append(raw)
             gpicks.append(resample_indices(raw.shape[0], self.num_points))
+        if self.device is not None:
+            return ([resample_on_device(f, p, self.device) for f, p in zip(frames, picks)],
+                    [resample_on_device(f, p, self.device) for f, p in zip(gts, gpicks)])
         inp = [torch.from_numpy(f[p, :].astype("float32")) for f, p in zip(frames, picks)]
         gt = [torch.from_numpy(f[p, :].astype("float32")) for f, p in zip(gts, gpicks)]
         return inp, gt

@@ -61,3 +61,23 @@ def test_evaluate_loop_on_synthetic_files(tmp_path):
     np.random.seed(0)
     res = data.evaluate(hc.build_model("cuda:0"), DataLoader(ds, batch_size=1), device="cuda:0")
     assert res["sequences"] == 1 and all(np.isfinite(res["chamfer"])) and all(np.isfinite(res["emd"])) and res["seconds_per_forward"] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_side_resampling_is_identical_to_the_host_path(tmp_path):
+    """data/no_norm_datasets.py:52-55 with the row selection on the GPU: same np.random call order, so the same sample bit
+    for bit (subset without replacement, and all-points-then-fill-with-replacement for short frames), and it feeds evaluate()."""
+    from torch.utils.data import DataLoader
+    from tests import harness_checks as hc
+    root, lst, _ = make_files(tmp_path)
+    np.random.seed(77)
+    want_in, want_gt = data.NLDriveDataset(root, lst, num_points=8192)[0]
+    np.random.seed(77)
+    got_in, got_gt = data.NLDriveDataset(root, lst, num_points=8192, device="cuda:0")[0]
+    for a, b in zip(want_in + want_gt, got_in + got_gt):
+        assert b.is_cuda and b.dtype == torch.float32 and torch.equal(a, b.cpu())
+    root2, lst2, _ = make_files(tmp_path / "small" if (tmp_path / "small").mkdir() is None else tmp_path, sizes=(2500, 2048, 2048, 2100, 2048, 2048, 1500))
+    ds = data.NLDriveDataset(root2, lst2, num_points=2048, device="cuda:0")
+    np.random.seed(0)
+    res = data.evaluate(hc.build_model("cuda:0"), DataLoader(ds, batch_size=1), device="cuda:0")
+    assert res["sequences"] == 1 and all(np.isfinite(res["chamfer"]))

@@ -9,7 +9,8 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- $B > "$out/trace_bench.json" 2> "$out/trace.err"
-cp "$out"/trace/t_kernel_stats.csv "$out/kernel_stats.csv" 2>/dev/null || find "$out/trace" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
+db=$(find "$out/trace" -name '*.db' | head -1)
+python3 tools/rocpd_stats.py "$db" "$out/kernel_stats.csv" "$out/step_by_queue.txt" > /dev/null
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o f -- $B > "$out/pmc_fetch.log" 2>&1
 echo "fetch done"
