@@ -205,20 +205,27 @@ int mcp_pointconv_agg(int b, int n, int s, int d, int k, const float *s_xyz, con
 int mcp_attention_small(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
                         const float *v, int v_stride, float scale, float *out, int out_stride, mcp_stream_t stream);
 
+/* Same contract for wide heads, hd in {32, 64, 256} (EI cross-former of level 3, mocopci.py:72-86 at dim 256 / 8 heads;
+ * Cross_Frame_Att, mocopci.py:499-522, whose head slots are C = 256 wide): S = QK^T and PV both on fp32 MFMA, online softmax,
+ * K/V streamed through LDS in 32-key tiles; nothing of size Nq x Nk is written. */
+int mcp_attention_wide(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
+                        const float *v, int v_stride, float scale, float *out, int out_stride, mcp_stream_t stream);
+
 /* chamfer_loss (models/utils.py:36-45 -> pytorch3d chamfer_distance defaults): per-point squared
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
 
 /* Point-Transformer vector attention (TransformerBlock.forward, models/pointT_layer2.py:58-77; d_model 64, k 16) after the
- * neighbour search and the q/k/v projections: xyz (B,N,3), q/kf/vf (B,N,64) channel-last (16-byte aligned), idx (B,N,16)
+ * neighbour search and the q/k/v projections: xyz (B,N,3), q/kf/vf (B,N,64) channel-last (16-byte aligned) with a common row
+ * stride of qkv_stride floats (64 for separate tensors, 192 when they are slices of one packed projection), idx (B,N,16)
  * -> out (B,N,64) = sum_j softmax_j(fc_gamma(q_i - k_j + delta_j) / 8) * (v_j + delta_j), delta_j = fc_delta(xyz_i - xyz_j).
  * fc_delta = Linear(3,64) ReLU Linear(64,64) as (wd1,bd1,wd2,bd2); fc_gamma = Linear(64,64) ReLU Linear(64,64) as
  * (wg1,bg1,wg2,bg2); packed once per block by mcp_ptblock_pack (mcp_ptblock_packed_floats() floats, caller-owned). */
 int mcp_ptblock_packed_floats(void);
 int mcp_ptblock_pack(const float *wd1, const float *bd1, const float *wd2, const float *bd2, const float *wg1, const float *bg1,
                      const float *wg2, const float *bg2, float *packed, mcp_stream_t stream);
-int mcp_ptblock_attention(int b, int n, int c, int k, const float *xyz, const float *q, const float *kf, const float *vf,
-                          const int *idx, const float *packed, float *out, mcp_stream_t stream);
+int mcp_ptblock_attention(int b, int n, int c, int k, int qkv_stride, const float *xyz, const float *q, const float *kf,
+                          const float *vf, const int *idx, const float *packed, float *out, mcp_stream_t stream);
 
 /* Approximate Earth Mover's Distance (metric of test.py:90): approxmatch + matchcost of
  * models/EMD/cuda/emd_kernel.cu:29-162, :204-247 (emd_cuda.approxmatch_forward / matchcost_forward, emd.py:11-12).

@@ -49,10 +49,11 @@ SIGNATURES = {
     "mcp_cross_volume": [_i] * 5 + [_p] * 8,
     "mcp_pointconv_agg": [_i] * 5 + [_p] * 12,
     "mcp_attention_small": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
+    "mcp_attention_wide": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
     "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_ptblock_packed_floats": [],
     "mcp_ptblock_pack": [_p] * 10,
-    "mcp_ptblock_attention": [_i] * 4 + [_p] * 8,
+    "mcp_ptblock_attention": [_i] * 5 + [_p] * 8,
     "mcp_emd": [_i, _i, _i, _p, _p, _p, _p, _p, _p],
     "mcp_prof_enable": [_i],
     "mcp_prof_collect": [_i, _p, _p],

@@ -90,7 +90,7 @@ __device__ __forceinline__ void layer64(const float *lds, int off_w, int off_b, 
     }
 }
 
-__global__ __launch_bounds__(64 * WAVES, 2) void ptblock_kernel(long long total, int n, const float *__restrict__ xyz,
+__global__ __launch_bounds__(64 * WAVES, 2) void ptblock_kernel(long long total, int n, int rs, const float *__restrict__ xyz,
                                                                  const float *__restrict__ q, const float *__restrict__ kf,
                                                                  const float *__restrict__ vf, const int *__restrict__ idx,
                                                                  const float *__restrict__ packed, float scale_log2e,
@@ -125,9 +125,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ptblock_kernel(long long total,
         }
         layer64(lds, OFF_D2, OFF_BD2, lane, h, d1, delta, false);
         // g = (q_i - k_j) + delta_j, rows loaded straight into accumulator layout
-        const float4 *qrow = reinterpret_cast<const float4 *>(q + p * C);
-        const float4 *krow = reinterpret_cast<const float4 *>(kf + ((long long)bb * n + id) * C);
-        const float4 *vrow = reinterpret_cast<const float4 *>(vf + ((long long)bb * n + id) * C);
+        // rs: row stride of q / k / v in floats (C when they are separate tensors, 3C when they are the packed projection)
+        const float4 *qrow = reinterpret_cast<const float4 *>(q + p * rs);
+        const float4 *krow = reinterpret_cast<const float4 *>(kf + ((long long)bb * n + id) * rs);
+        const float4 *vrow = reinterpret_cast<const float4 *>(vf + ((long long)bb * n + id) * rs);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -180,16 +181,17 @@ MCP_EXPORT int mcp_ptblock_pack(const float *wd1, const float *bd1, const float 
     return mcp_launch_status();
 }
 
-MCP_EXPORT int mcp_ptblock_attention(int b, int n, int c, int k, const float *xyz, const float *q, const float *kf, const float *vf,
-                                     const int *idx, const float *packed, float *out, mcp_stream_t stream) {
+MCP_EXPORT int mcp_ptblock_attention(int b, int n, int c, int k, int qkv_stride, const float *xyz, const float *q, const float *kf,
+                                     const float *vf, const int *idx, const float *packed, float *out, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && q && kf && vf && idx && packed && out);
     if (c != C || k != KNB) return MCP_ERR_UNSUPPORTED;
+    if (qkv_stride < C || (qkv_stride & 3)) return MCP_ERR_BAD_ARG;
     if ((((uintptr_t)q) | ((uintptr_t)kf) | ((uintptr_t)vf) | ((uintptr_t)out) | ((uintptr_t)packed)) & 15) return MCP_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)b * n;
     const long long want = ((total + 1) / 2 + WAVES * 4 - 1) / (WAVES * 4);  // >= 4 point pairs per wave: amortises the weight staging
     const unsigned grid = (unsigned)max(1LL, min(want, 768LL));
     const float scale_log2e = 1.44269504088896340736f / 8.0f;  // softmax(attn / sqrt(64)), pointT_layer2.py:73
-    hipLaunchKernelGGL(ptblock_kernel, dim3(grid), dim3(64 * WAVES), 0, s, total, n, xyz, q, kf, vf, idx, packed, scale_log2e, out);
+    hipLaunchKernelGGL(ptblock_kernel, dim3(grid), dim3(64 * WAVES), 0, s, total, n, qkv_stride, xyz, q, kf, vf, idx, packed, scale_log2e, out);
     return mcp_launch_status();
 }

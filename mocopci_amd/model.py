@@ -328,7 +328,17 @@ class MoCoPCI(nn.Module):
         res2 = self.lin(F.gelu(self.lin(h, e + ".ffn.fc1")), e + ".ffn.fc2")
         return F.linear(torch.cat([res1, res2], dim=-1), self.W(prefix + ".pj"))
 
-    def cross_frame_att(self, prefix, x):
+    def folded_tail(self, fc2, mapping):
+        """mapping(fc2(h)) as ONE affine map: W = Wmap Wfc2, b = Wmap bfc2 + bmap (cached).  Used where only the 3-channel
+        flow is read downstream and the block's feature output is not (inference)."""
+        P = self._params()
+        key = ("tail", fc2, mapping)
+        if key not in P:
+            wm, bm = self.W(mapping), self.Bv(mapping)
+            P[key] = ((wm @ self.W(fc2)).contiguous(), (wm @ self.Bv(fc2) + bm).contiguous())
+        return P[key]
+
+    def cross_frame_att(self, prefix, x, feats=True):
         """Cross_Frame_Att.forward (mocopci.py:499-522) batched over samples.  x (B,2,N,C) holds the two
         frames' features; the block's attention runs 4 heads of width C and sums over the two frames,
         so its 4 head slots come out as 4 'frames' (mocopci.py:619-621); the first is dropped."""
@@ -344,16 +354,18 @@ class MoCoPCI(nn.Module):
             sl = lambda t: None if t is None else torch.cat([t[C:4 * C], t[5 * C:8 * C]], dim=0).contiguous()
             P[key] = (wq[C:].contiguous(), None if bq is None else bq[C:].contiguous(), sl(wkv), sl(bkv))
         wq, bq, wkv, bkv = P[key]
-        q = F.linear(xn, wq, bq).reshape(B * Fr, N, 3, C).permute(0, 2, 1, 3)
-        kv = F.linear(xr, wkv, bkv).reshape(B * Fr, N, 2, 3, C).permute(2, 0, 3, 1, 4)
-        o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=C ** -0.5)      # (B*2,3,N,C)
-        o = self.lin(o.reshape(B, Fr, 3, N, C).sum(dim=1), a + ".proj")           # (B,3,N,C)
+        o = ops.backend().attention(F.linear(xn, wq, bq).reshape(B * Fr, N, 3 * C), F.linear(xr, wkv, bkv).reshape(B * Fr, N, 6 * C), 3,
+                                    scale=C ** -0.5)                              # (B*2,N,3C): 3 head slots, each C wide
+        o = self.lin(o.reshape(B, Fr, N, 3, C).sum(dim=1).transpose(1, 2), a + ".proj")   # (B,3,N,C)
         t = prefix + ".trans_block_2"
-        xa = self.lin(F.prelu(self.lin(o, t + ".fc1"), P[t + ".act.weight"]), t + ".fc2")
+        hid = F.prelu(self.lin(o, t + ".fc1"), P[t + ".act.weight"])
+        if not feats:  # only the flows are read (MultiFrameEstimatier.forward never uses cross_block3's features in inference)
+            return None, F.linear(hid, *self.folded_tail(t + ".fc2", prefix + ".mapping_xyz"))
+        xa = self.lin(hid, t + ".fc2")
         frames = self.lin(xa, prefix + ".mapping_xyz")
         return xa, frames                                                         # (B,3,N,C), (B,3,N,3)
 
-    def mlp_t(self, prefix, x):
+    def mlp_t(self, prefix, x, tail=None):
         """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2.  The depthwise k=1 conv is a
         per-channel scale + bias, folded into fc1 once: (W x + b) * s + t = (s W) x + (s b + t)."""
         P = self._params()
@@ -363,9 +375,12 @@ class MoCoPCI(nn.Module):
             P[key] = ((self.W(prefix + ".fc1") * sc[:, None]).contiguous(),
                       (self.Bv(prefix + ".fc1") * sc + P[prefix + ".dwconv.dwconv.bias"]).contiguous())
         w1, b1 = P[key]
-        return self.lin(F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"]), prefix + ".fc2")
+        hid = F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"])
+        if tail is not None:
+            return F.linear(hid, *self.folded_tail(prefix + ".fc2", tail))
+        return self.lin(hid, prefix + ".fc2")
 
-    def multi_frame_att(self, prefix, x, heads=8, rows=None):
+    def multi_frame_att(self, prefix, x, heads=8, rows=None, feats=True):
         """Multi_Frame_Att.forward (mocopci.py:551-575) batched, on the INNER frames only.  The reference runs 5 frames
         and returns frames[:, 1:-1].  Every operator in between is per frame and per point (eval-mode BatchNorm, 1x1
         convs, PReLU) except the attention, which pairs frame f with frame 4-f of the flipped stack: the inner three pair
@@ -384,6 +399,8 @@ class MoCoPCI(nn.Module):
         xn = xn + o
         xb = self.mlp_t(prefix + ".mlp", self.bn_eval(xn, prefix + ".norm2", 1e-5))
         x = x + xb
+        if not feats:  # flows only: trans_block.fc2 and mapping_xyz collapse into one (4C -> 3) map
+            return None, self.mlp_t(prefix + ".trans_block", x, tail=prefix + ".mapping_xyz")
         xf = self.mlp_t(prefix + ".trans_block", x)                               # (B,3,N,latent)
         frames = self.lin(xf, prefix + ".mapping_xyz")                            # (B,3,N,3)
         return xf, frames
@@ -475,26 +492,38 @@ class MoCoPCI(nn.Module):
         x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                            # (B,3,N,C)
         # (the block's third output, downsample(x_f), is never read by MultiFrameEstimatier.forward in inference)
         if rows is not None:  # only some (sample, frame) flows are read downstream
-            _, frames = self.multi_frame_att(prefix + ".cross_block", x, rows=rows)
+            _, frames = self.multi_frame_att(prefix + ".cross_block", x, rows=rows, feats=False)
             return frames[:, 0], n1, n2                                            # (len(rows),N,3)
-        _, frames = self.multi_frame_att(prefix + ".cross_block", x)               # (B,3,N,3)
+        _, frames = self.multi_frame_att(prefix + ".cross_block", x, feats=False)  # (B,3,N,3)
         return frames, n1, n2
+
+    def qkv_projection(self, prefix, feats):
+        """TransformerBlock's x = fc1(features); q, k, v = w_qs(x), w_ks(x), w_vs(x) (pointT_layer2.py:62-66; the three
+        projections have no bias and nothing else reads x) as ONE (C -> 3C) affine map: W = [Wq; Wk; Wv] W1, b = [..] b1.
+        Returns the packed (B,N,3C) tensor [q | k | v]."""
+        P = self._params()
+        key = ("qkv_fold", prefix)
+        if key not in P:
+            w3 = torch.cat([self.W(prefix + w) for w in (".w_qs", ".w_ks", ".w_vs")], dim=0)
+            P[key] = ((w3 @ self.W(prefix + ".fc1")).contiguous(), (w3 @ self.Bv(prefix + ".fc1")).contiguous())
+        return F.linear(feats, *P[key])
 
     def transformer_block(self, prefix, feats, xyz, k=16, qkv=None):
         """TransformerBlock.forward (pointT_layer2.py:58-77): vector attention over the 16 nearest
-        neighbours (direct squared distance; the reference's full argsort is replaced by the KNN kernel)."""
+        neighbours (direct squared distance; the reference's full argsort is replaced by the KNN kernel).
+        qkv: the packed (B,N,3C) projections when the caller already has them."""
         be = ops.backend()
         idx = be.knn(xyz, xyz, k, mode=ops.MCP_DIST_DIRECT)
         if qkv is None:
-            x = self.lin(feats, prefix + ".fc1")
-            qkv = [self.lin(x, prefix + w) for w in (".w_qs", ".w_ks", ".w_vs")]
+            qkv = self.qkv_projection(prefix, feats)
+        C = feats.shape[-1]
         P = self._params()
         key = ("ptblock_pack", be.name, prefix)
         if key not in P:
             P[key] = be.ptblock_pack(self.W(prefix + ".fc_delta.0"), self.Bv(prefix + ".fc_delta.0"), self.W(prefix + ".fc_delta.2"),
                                      self.Bv(prefix + ".fc_delta.2"), self.W(prefix + ".fc_gamma.0"), self.Bv(prefix + ".fc_gamma.0"),
                                      self.W(prefix + ".fc_gamma.2"), self.Bv(prefix + ".fc_gamma.2"))
-        res = be.ptblock_attention(xyz, qkv[0], qkv[1], qkv[2], idx, P[key])
+        res = be.ptblock_attention(xyz, qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], idx, P[key])
         return self.lin(res, prefix + ".fc2") + feats
 
     def folded_conv_bn(self, conv, bn, eps):
@@ -547,7 +576,7 @@ class MoCoPCI(nn.Module):
         new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
         # cross_block3, both directions at once (mocopci.py:853-856)
         xs = torch.stack([new3, sw(new3)], dim=1)                                  # (2B,2,N3,C)
-        feats3s, frame3s = self.cross_frame_att(m + "cross_block3", xs)            # (2B,3,N3,C),(2B,3,N3,3)
+        _, frame3s = self.cross_frame_att(m + "cross_block3", xs, feats=False)     # (2B,3,N3,3)
         f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
 
         # Which level-1 flows are read: l0 (below) uses, of the 2B samples x 3 frames, the forward branch's frames 0,1 and
@@ -610,13 +639,12 @@ class MoCoPCI(nn.Module):
             be = ops.backend()
             t = m + "shape1"
             dfeat_all = self.pointconv(m + "level1", warped, warped, wf, idx=idx_self)
-            x_all = self.lin(dfeat_all, t + ".fc1")
-            proj_all = [self.lin(x_all, t + w) for w in (".w_qs", ".w_ks", ".w_vs")]
+            qkv_all = self.qkv_projection(t, dfeat_all)                           # (3B,N,192)
             main.wait_event(done)
             # the 3-NN search of the upsampling below needs only (warped, down): it runs beside the Point-Transformer kernel
             early.launch("i3_refine", lambda: be.interp3_search(warped, down), lane=1)
             dfeat = be.group_rows(dfeat_all, sel)
-            shape = self.transformer_block(t, dfeat, down, qkv=[be.group_rows(v, sel) for v in proj_all])
+            shape = self.transformer_block(t, dfeat, down, qkv=be.group_rows(qkv_all, sel))
             upf = be.interp3_apply(shape, *early.get("i3_refine"))
         else:
             # down = warped[sel]: its 32 nearest in warped are rows of the self search the fusion stage needs anyway

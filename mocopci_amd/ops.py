@@ -296,10 +296,15 @@ class HipBackend:
         return packed
 
     def ptblock_attention(self, xyz, q, k, v, idx, packed):
-        """Vector attention of TransformerBlock.forward (pointT_layer2.py:68-75) after knn + projections: -> (B,N,64)."""
+        """Vector attention of TransformerBlock.forward (pointT_layer2.py:68-75) after knn + projections: -> (B,N,64).
+        q, k, v: (B,N,64) tensors, or last-axis slices of one packed (B,N,192) projection (read in place through the row stride)."""
         B, N, C = q.shape
+        rs = q.stride(1)
+        for t in (q, k, v):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.shape == (B, N, C) and t.stride() == (N * rs, rs, 1)):
+                raise RuntimeError("q, k, v must be float32 CUDA tensors of one shape with unit channel stride and a common row stride")
         out = torch.empty((B, N, C), dtype=torch.float32, device=q.device)
-        _call("mcp_ptblock_attention", q, B, N, C, idx.shape[-1], _lib.fptr(xyz), _lib.fptr(q), _lib.fptr(k), _lib.fptr(v), _lib.iptr(idx),
+        _call("mcp_ptblock_attention", q, B, N, C, idx.shape[-1], rs, _lib.fptr(xyz), q.data_ptr(), k.data_ptr(), v.data_ptr(), _lib.iptr(idx),
               _lib.fptr(packed), _lib.fptr(out))
         return out
 
@@ -320,17 +325,13 @@ class HipBackend:
         hd = C // heads
         if scale is None:
             scale = hd ** -0.5
-        if hd in (8, 16):
-            _lib.fptr(q), _lib.fptr(kv)
-            out = torch.empty((BF, Nq, C), dtype=torch.float32, device=q.device)
-            _call("mcp_attention_small", q, BF, Nq, Nk, heads, hd, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
-                  float(scale), out.data_ptr(), C)
-            return out
-        # larger head dims (ei3: 32, cross-frame block: 256) are ordinary dense attention: library kernel
-        qh = q.reshape(BF, Nq, heads, hd).permute(0, 2, 1, 3)
-        kvh = kv.reshape(BF, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
-        o = torch.nn.functional.scaled_dot_product_attention(qh, kvh[0], kvh[1], scale=scale)
-        return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
+        _lib.fptr(q), _lib.fptr(kv)
+        out = torch.empty((BF, Nq, C), dtype=torch.float32, device=q.device)
+        # head dims 8/16: S on MFMA, P.V on packed FMAs; 32/64/256 (ei3, Cross_Frame_Att): both products on MFMA
+        name = "mcp_attention_small" if hd in (8, 16) else "mcp_attention_wide"
+        _call(name, q, BF, Nq, Nk, heads, hd, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
+              float(scale), out.data_ptr(), C)
+        return out
 
     def chamfer(self, x, y):
         """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor."""

@@ -370,7 +370,8 @@ def test_knn_pruned_clustered_and_degenerate_clouds():
         assert torch.equal(i1, i2) and torch.equal(d1, d2)
 
 
-@pytest.mark.parametrize("bf,nq,nk,heads,hd", [(4, 2048, 2048, 8, 8), (6, 512, 512, 8, 16), (2, 300, 777, 4, 8), (1, 33, 70, 2, 16)])
+@pytest.mark.parametrize("bf,nq,nk,heads,hd", [(4, 2048, 2048, 8, 8), (6, 512, 512, 8, 16), (2, 300, 777, 4, 8), (1, 33, 70, 2, 16),
+                                               (3, 256, 256, 8, 32), (4, 256, 256, 3, 256), (2, 100, 333, 2, 64), (1, 40, 50, 1, 256)])
 def test_attention_small_matches_fp32_reference(bf, nq, nk, heads, hd):
     from oracle.backend import OracleBackend
     g = torch.Generator().manual_seed(nq + hd)
@@ -415,8 +416,13 @@ def test_ptblock_attention_matches_unfused_oracle(n):
     ob = OracleBackend()
     want = ob.ptblock_attention(xyz, q, k, v, idx, ob.ptblock_pack(*ws))
     be = ops.backend()
-    got = be.ptblock_attention(*[t.to(DEV) for t in (xyz, q, k, v, idx)], be.ptblock_pack(*[w.to(DEV) for w in ws])).cpu()
+    packed = be.ptblock_pack(*[w.to(DEV) for w in ws])
+    got = be.ptblock_attention(*[t.to(DEV) for t in (xyz, q, k, v, idx)], packed).cpu()
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+    # q, k, v read in place as slices of one packed (B,N,192) projection (row stride 192): identical result
+    qkv = torch.cat([q, k, v], dim=-1).to(DEV)
+    got2 = be.ptblock_attention(xyz.to(DEV), qkv[..., :64], qkv[..., 64:128], qkv[..., 128:], idx.to(DEV), packed).cpu()
+    assert torch.equal(got, got2)
 
 
 def test_grouping_modules_match_reference_classes(golden_dir):
