@@ -20,12 +20,15 @@
 // D = 256 (cross3, pointconv_util.py:783-791): the 256 KB weight image does not fit the CU's 160 KB of LDS, so the output
 // channels are split over blockIdx.y into two halves of four 32-channel tiles (128 KB of weights resident per workgroup);
 // each half rebuilds x0 from its own gather (an L2-resident 32 KB per point) rather than exchanging it.
+// D = 64 / 128: the D -> D layer runs on the bf16 matrix pipe through the exact three-way operand split of mfma_split.h (six
+// bf16 MFMAs per 16 k-values instead of eight f32-input ones); the weight pieces are prepared once by mcp_cross_pack, x0 is
+// split in registers as layer 1 leaves it.  D = 256 keeps the f32-input MFMA (its split image would need four LDS passes).
 #include "common.h"
+#include "mfma_split.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int WAVES = 4;
 constexpr int KNB = 32;
 constexpr float SLOPE = 0.1f;  // pointconv_util.py:10
 
@@ -84,7 +87,9 @@ __device__ __forceinline__ int scatter_reg(int lane) { return ((lane >> 4) & 1) 
 template <int D>
 struct CrossLds {
     static constexpr int T = D / 32;
-    static constexpr int W_FLOATS = T * (T * 16 / 4) * 64 * 4;  // [t_out][kquad][lane][4]  = D*D
+    static constexpr bool BF = D != 256;  // D -> D layer on the split-bf16 path
+    // f32 image [t_out][kquad][lane][4] = D*D floats; split image [t_out][kstep = 2T][piece = 3][lane] x uint4 = 1.5 D*D floats
+    static constexpr int W_FLOATS = BF ? T * (2 * T) * 3 * 64 * 4 : T * (T * 16 / 4) * 64 * 4;
     static constexpr int POS_FLOATS = T * 2 * 64;               // [t][kstep][lane]
     static constexpr int B_FLOATS = T * 2 * 16;                 // [t][half][r]
     static constexpr int OFF_W = 0, OFF_POS = W_FLOATS, OFF_B = OFF_POS + POS_FLOATS;
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(256) void cross_pack_kernel(const float *__restrict
     for (int e = blockIdx.x * 256 + threadIdx.x; e < L::FLOATS; e += gridDim.x * 256) {
         float v;
         if (e < L::OFF_POS) {  // [t][q][lane][4]: k-step s = 4q + j -> input tile s >> 4, register s & 15
+            if (L::BF) continue;  // written below as split pieces
             const int j = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % KQ, t = (e >> 8) / KQ;
             const int s = 4 * q + j, tin = s >> 4, r = s & 15;
             v = wmlp[(32 * t + (lane & 31)) * D + 32 * tin + chan_of(r, lane >> 5)];
@@ -115,18 +121,28 @@ __global__ __launch_bounds__(256) void cross_pack_kernel(const float *__restrict
         }
         packed[e] = v;
     }
+    if (L::BF) mcp_split_weights(reinterpret_cast<uint4 *>(packed + L::OFF_W), wmlp, D, T, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // The kernel is latency-bound (one point in flight per wave through idx -> gathers -> MFMA -> reduce), so residency
 // matters more than unrolling: the output-tile loop is kept rolled and registers are capped for 3 (D=64) / 2 (D=128)
 // waves per SIMD.
+// Workgroup shape per D: the split image of D = 128 is 98 KB, one workgroup per CU, so that one carries 8 waves (2 per SIMD).
+template <int D>
+struct CrossShape {
+    static constexpr int NW = D == 128 ? 8 : 4;
+    static constexpr int WG_PER_CU = D == 64 ? 3 : 1;
+    static constexpr int GRID = D == 64 ? 768 : 256;
+};
+
 template <int D, int SPLIT>
-__global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : D == 128 ? 2 : 1)) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
+__global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
                                                            const float *__restrict__ xyz2, const float *__restrict__ points1,
                                                            const float *__restrict__ points2, const int *__restrict__ idx,
                                                            const float *__restrict__ packed, float *__restrict__ out) {
     using L = CrossLds<D>;
-    constexpr int T = L::T, KQ = T * 4;  // k-quads per output tile
+    constexpr int T = L::T, KQ = T * 4;  // k-quads per output tile (f32 image)
+    constexpr int WAVES = CrossShape<D>::NW;
     constexpr int TO = T / SPLIT;        // output tiles of this workgroup: TO * split .. TO * split + TO - 1
     constexpr int WH = L::W_FLOATS / SPLIT, SMALL = L::POS_FLOATS + L::B_FLOATS;  // LDS image: [this half of W | pos | bias]
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -174,7 +190,8 @@ __global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : D == 128 ? 2 : 1)) void 
         if (pn < total) idn = idx[pn * KNB + col];
     }
     for (; p < total; p = pn, pn += stride) {
-        f32x16 x0[T];
+        f32x16 x0[L::BF ? 1 : T];
+        McpSplit3 xs[L::BF ? 2 * T : 1];
         const float4 *row1 = reinterpret_cast<const float4 *>(points1 + p * D);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -193,7 +210,12 @@ __global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : D == 128 ? 2 : 1)) void 
                 acc[4 * g + 2] = leaky(acc[4 * g + 2] + rg[t][g].z);
                 acc[4 * g + 3] = leaky(acc[4 * g + 3] + rg[t][g].w);
             }
-            x0[t] = acc;
+            if (L::BF) {
+                xs[L::BF ? 2 * t : 0] = mcp_split_kstep(acc, 0);
+                xs[L::BF ? 2 * t + 1 : 0] = mcp_split_kstep(acc, 1);
+            } else {
+                x0[L::BF ? 0 : t] = acc;
+            }
         }
         if (pn < total) {
             fetch(pn, idn);
@@ -205,14 +227,20 @@ __global__ __launch_bounds__(64 * WAVES, (D == 64 ? 3 : D == 128 ? 2 : 1)) void 
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = lbias[(t * 2 + h) * 16 + r];
+            if (L::BF) {
+                const uint4 *ws = reinterpret_cast<const uint4 *>(lds) + (size_t)tl * (2 * T) * 3 * 64 + lane;
 #pragma unroll
-            for (int q4 = 0; q4 < KQ; ++q4) {
-                const float4 w = wq[(tl * KQ + q4) * 64 + lane];
-                const int tin = q4 >> 2, r0 = (q4 & 3) * 4;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x0[tin][r0 + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x0[tin][r0 + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x0[tin][r0 + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x0[tin][r0 + 3], acc, 0, 0, 0);
+                for (int s2 = 0; s2 < 2 * T; ++s2) acc = mcp_mfma_split(ws + (size_t)s2 * 3 * 64, xs[L::BF ? s2 : 0], acc);
+            } else {
+#pragma unroll
+                for (int q4 = 0; q4 < KQ; ++q4) {
+                    const float4 w = wq[(tl * KQ + q4) * 64 + lane];
+                    const int tin = L::BF ? 0 : q4 >> 2, r0 = (q4 & 3) * 4;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x0[tin][r0 + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x0[tin][r0 + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x0[tin][r0 + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x0[tin][r0 + 3], acc, 0, 0, 0);
+                }
             }
             const float m = leaky(scatter_max(acc, lane));  // leaky is monotone: it commutes with the max
             if ((lane & 1) == 0) out[p * D + 32 * t + chan_of(scatter_reg(lane), h)] = m;
@@ -230,11 +258,12 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+    constexpr int WAVES = CrossShape<D>::NW;
     // at least 8 points per wave so the weight staging is amortised
     const long long want = (total + WAVES * 8 - 1) / (WAVES * 8);
     // persistent-style grid = exactly the resident slots (256 CUs x 3 or 2 workgroups, see __launch_bounds__): a larger
     // grid leaves a partly filled second round of workgroups
-    const unsigned grid = (unsigned)max(1LL, min(want, (long long)(D == 64 ? 768 : D == 128 ? 512 : 256 / SPLIT)));
+    const unsigned grid = (unsigned)max(1LL, min(want, (long long)(CrossShape<D>::GRID / SPLIT)));
     hipLaunchKernelGGL(kern, dim3(grid, SPLIT), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out);
     return mcp_launch_status();
 }

@@ -17,18 +17,14 @@
 //   * softmax over the 64 neighbours and the weighted coordinate sum are wave reductions.
 // Per point: 392 MFMAs (1.6 MFLOP); HBM traffic is the compulsory idx + coordinates + output.
 //
-// fp32 on the bf16 matrix pipe (default; MCP_FUSION_F32_MFMA=1 selects the f32-input MFMA build for A/B runs).  The f32-input
-// MFMA runs at 1/16 of the bf16 rate, so layers 2 and 3 evaluate every fp32 product from an EXACT three-way split of both
-// operands: x = x1 + x2 + x3 with x1 = top 16 bits of x, x2 = top 16 bits of (x - x1), x3 = x - x1 - x2 (8 significant bits
-// each, every piece exactly a bf16, both subtractions exact).  a.b = a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 + O(2^-24 |a.b|):
-// six v_mfma_f32_32x32x16_bf16 (exact 8x8-bit products, fp32 accumulation) per 16 k-values instead of eight
-// v_mfma_f32_32x32x2_f32 -- 6/16 of the MFMA time at the same accuracy class (measured against the f32-MFMA build and the CPU
-// oracle in the tests).  The weight pieces are split once while staging to LDS; an activation tile is split in registers
-// (and / subtract / v_perm pack) right where the previous layer's ReLU leaves it, in the accumulator layout, so the
-// accumulator-as-operand chaining is unchanged: k-step s of an input tile takes registers 8s..8s+7 of both lane halves.
+// fp32 on the bf16 matrix pipe (default; MCP_FUSION_F32_MFMA=1 selects the f32-input MFMA build for A/B runs): layers 2 and 3
+// evaluate every fp32 product from the exact three-way bf16 split of mfma_split.h -- six bf16 MFMAs per 16 k-values instead
+// of eight f32-input ones.  The weight pieces are split once while staging to LDS; an activation tile is split in registers
+// right where the previous layer's ReLU leaves it, in the accumulator layout.
 #include <stdlib.h>
 
 #include "common.h"
+#include "mfma_split.h"
 
 namespace {
 
@@ -180,71 +176,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_kernel(long long total, 
 
 
 // ---- split-bf16 build ------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// LDS image of the split build (bytes): w1 / biases as above (fp32), then per layer [t_out][kstep][piece][lane] x 16 B
+// LDS image of the split build: w1 / biases as above (fp32), then per layer [t_out][kstep][piece][lane] x 16 B
 constexpr int SP_W1 = 0, SP_B1 = 256, SP_B2 = SP_B1 + 64, SP_B3 = SP_B2 + 64, SP_F32_FLOATS = SP_B3 + 128;  // fp32 part (floats)
 constexpr int SP_W2_U4 = 2 * 4 * 3 * 64, SP_W3_U4 = 4 * 4 * 3 * 64;                                         // uint4 counts
 constexpr size_t SP_LDS_BYTES = SP_F32_FLOATS * 4 + (size_t)(SP_W2_U4 + SP_W3_U4) * 16;
-
-__device__ __forceinline__ uint32_t top16(float x) { return __float_as_uint(x) & 0xFFFF0000u; }
-// (hi16(odd) << 16) | hi16(even): two bf16 pieces in one dword, element 2j in the low half
-__device__ __forceinline__ uint32_t pack_hi(float even, float odd) {
-    return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
-}
-
-struct Split3 {  // the three bf16 pieces of one k-step's 8 values per lane (4 dwords each)
-    uint4 p1, p2, p3;
-};
-// exact 3-way split of registers 8s..8s+7 of an accumulator tile
-__device__ __forceinline__ Split3 split_kstep(const f32x16 &a, int s) {
-    float r1[8], r2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float x = a[8 * s + i];
-        r1[i] = x - __uint_as_float(top16(x));            // exact: x and its top 16 bits share sign and exponent
-        r2[i] = r1[i] - __uint_as_float(top16(r1[i]));    // exact; at most 8 significant bits remain
-    }
-    Split3 o;
-    o.p1 = make_uint4(pack_hi(a[8 * s + 0], a[8 * s + 1]), pack_hi(a[8 * s + 2], a[8 * s + 3]), pack_hi(a[8 * s + 4], a[8 * s + 5]),
-                      pack_hi(a[8 * s + 6], a[8 * s + 7]));
-    o.p2 = make_uint4(pack_hi(r1[0], r1[1]), pack_hi(r1[2], r1[3]), pack_hi(r1[4], r1[5]), pack_hi(r1[6], r1[7]));
-    o.p3 = make_uint4(pack_hi(r2[0], r2[1]), pack_hi(r2[2], r2[3]), pack_hi(r2[4], r2[5]), pack_hi(r2[6], r2[7]));
-    return o;
-}
-__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// acc += W(k-step) . X(k-step) from the pieces, small terms first
-__device__ __forceinline__ f32x16 mfma_split(const uint4 *w, const Split3 &x, f32x16 acc) {
-    const uint4 w1 = w[0], w2 = w[64], w3 = w[128];  // [piece][lane]
-    acc = mfma_bf16(w3, x.p1, acc);
-    acc = mfma_bf16(w1, x.p3, acc);
-    acc = mfma_bf16(w2, x.p2, acc);
-    acc = mfma_bf16(w2, x.p1, acc);
-    acc = mfma_bf16(w1, x.p2, acc);
-    acc = mfma_bf16(w1, x.p1, acc);
-    return acc;
-}
-
-// stage one layer's weights as split pieces: dst[((t * 4 + s) * 3 + piece) * 64 + lane] = 8 bf16 of
-// W[32t + (lane&31)][32 (s>>1) + chan_of(8 (s&1) + i, lane>>5)], i = 0..7
-__device__ __forceinline__ void stage_split(uint4 *dst, const float *__restrict__ w, int cin, int tiles, int tid) {
-    for (int e = tid; e < tiles * 4 * 64; e += 64 * WAVES) {
-        const int lane = e & 63, s = (e >> 6) & 3, t = e >> 8;
-        float v[8], r1[8], r2[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i] = w[(32 * t + (lane & 31)) * cin + 32 * (s >> 1) + chan_of(8 * (s & 1) + i, lane >> 5)];
-            r1[i] = v[i] - __uint_as_float(top16(v[i]));
-            r2[i] = r1[i] - __uint_as_float(top16(r1[i]));
-        }
-        uint4 *o = dst + (size_t)(t * 4 + s) * 3 * 64 + lane;
-        o[0] = make_uint4(pack_hi(v[0], v[1]), pack_hi(v[2], v[3]), pack_hi(v[4], v[5]), pack_hi(v[6], v[7]));
-        o[64] = make_uint4(pack_hi(r1[0], r1[1]), pack_hi(r1[2], r1[3]), pack_hi(r1[4], r1[5]), pack_hi(r1[6], r1[7]));
-        o[128] = make_uint4(pack_hi(r2[0], r2[1]), pack_hi(r2[2], r2[3]), pack_hi(r2[4], r2[5]), pack_hi(r2[6], r2[7]));
-    }
-}
 
 __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long total, int n, const float *__restrict__ p1,
                                                                   const float *__restrict__ p2, const int *__restrict__ idx,
@@ -260,8 +195,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
         const int lane = e & 63, s = (e >> 6) & 1, t = e >> 7;
         lds[SP_W1 + e] = w1[(32 * t + (lane & 31)) * 4 + 2 * s + (lane >> 5)];
     }
-    stage_split(w2s, w2, C1, 2, tid);
-    stage_split(w3s, w3, C2, 4, tid);
+    mcp_split_weights(w2s, w2, C1, 2, tid, 64 * WAVES);
+    mcp_split_weights(w3s, w3, C2, 4, tid, 64 * WAVES);
     for (int e = tid; e < 64; e += 64 * WAVES) {  // biases: [t][h][r]
         const int r = e & 15, h = (e >> 4) & 1, t = e >> 5;
         lds[SP_B1 + e] = b1[32 * t + chan_of(r, h)];
@@ -288,7 +223,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
             const float dist = sqrtf((rx * rx + ry * ry) + rz * rz);
             const float in0 = h ? ry : rx, in1 = h ? dist : rz;
             // ---- layer 1: 4 -> 64 on the f32-input MFMA (K = 4: two k-steps), split for layer 2 as it is produced ----
-            Split3 x1[4];
+            McpSplit3 x1[4];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x16 acc;
@@ -298,22 +233,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[SP_W1 + (t * 2 + 1) * 64 + lane], in1, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
-                x1[2 * t + 0] = split_kstep(acc, 0);
-                x1[2 * t + 1] = split_kstep(acc, 1);
+                x1[2 * t + 0] = mcp_split_kstep(acc, 0);
+                x1[2 * t + 1] = mcp_split_kstep(acc, 1);
             }
             // ---- layer 2: 64 -> 64 ----
-            Split3 x2[4];
+            McpSplit3 x2[4];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = lds[SP_B2 + (t * 2 + h) * 16 + r];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mfma_split(w2s + (size_t)(t * 4 + s) * 3 * 64 + lane, x1[s], acc);
+                for (int s = 0; s < 4; ++s) acc = mcp_mfma_split(w2s + (size_t)(t * 4 + s) * 3 * 64 + lane, x1[s], acc);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
-                x2[2 * t + 0] = split_kstep(acc, 0);
-                x2[2 * t + 1] = split_kstep(acc, 1);
+                x2[2 * t + 0] = mcp_split_kstep(acc, 0);
+                x2[2 * t + 1] = mcp_split_kstep(acc, 1);
             }
             // ---- layer 3: 64 -> 128, consumed into the channel max ----
             float m = 0.f;
@@ -323,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = lds[SP_B3 + (t * 2 + h) * 16 + r];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mfma_split(w3s + (size_t)(t * 4 + s) * 3 * 64 + lane, x2[s], acc);
+                for (int s = 0; s < 4; ++s) acc = mcp_mfma_split(w3s + (size_t)(t * 4 + s) * 3 * 64 + lane, x2[s], acc);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r]);
             }
