@@ -229,8 +229,7 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
             for (int r = 0; r < 16; ++r) acc[r] = lbias[(t * 2 + h) * 16 + r];
             if (L::BF) {
                 const uint4 *ws = reinterpret_cast<const uint4 *>(lds) + (size_t)tl * (2 * T) * 3 * 64 + lane;
-#pragma unroll
-                for (int s2 = 0; s2 < 2 * T; ++s2) acc = mcp_mfma_split(ws + (size_t)s2 * 3 * 64, xs[L::BF ? s2 : 0], acc);
+                acc = mcp_tile_split<(L::BF ? 2 * T : 1)>(ws, xs, acc);
             } else {
 #pragma unroll
                 for (int q4 = 0; q4 < KQ; ++q4) {

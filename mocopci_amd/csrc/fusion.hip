@@ -243,8 +243,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = lds[SP_B2 + (t * 2 + h) * 16 + r];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mcp_mfma_split(w2s + (size_t)(t * 4 + s) * 3 * 64 + lane, x1[s], acc);
+                acc = mcp_tile_split<4>(w2s + (size_t)t * 4 * 3 * 64 + lane, x1, acc);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
                 x2[2 * t + 0] = mcp_split_kstep(acc, 0);
@@ -257,8 +256,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = lds[SP_B3 + (t * 2 + h) * 16 + r];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mcp_mfma_split(w3s + (size_t)(t * 4 + s) * 3 * 64 + lane, x2[s], acc);
+                acc = mcp_tile_split<4>(w3s + (size_t)t * 4 * 3 * 64 + lane, x2, acc);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r]);
             }

@@ -12,6 +12,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef MCP_SPLIT_SCHED_MASK
+#define MCP_SPLIT_SCHED_MASK 0x0000
+#endif
+
 typedef float mcp_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 mcp_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -59,6 +63,31 @@ __device__ __forceinline__ mcp_f32x16 mcp_mfma_split(const uint4 *w, const McpSp
     acc = mcp_mfma_bf16(w1, x.p1, acc);
     return acc;
 }
+// One output tile over KSTEPS k-steps: acc += sum_s W(s) . X(s).  ws points at this lane's entry of (k-step 0, piece 1); k-steps
+// are 3 * 64 uint4 apart.  The weight pieces of step s+1 are read while the six MFMAs of step s run, and a scheduling barrier
+// per step keeps the compiler from hoisting every LDS read of the (unrolled) layer to its top, which costs ~100 registers.
+template <int KSTEPS>
+__device__ __forceinline__ mcp_f32x16 mcp_tile_split(const uint4 *ws, const McpSplit3 *xs, mcp_f32x16 acc) {
+    uint4 w1 = ws[0], w2 = ws[64], w3 = ws[128];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        uint4 n1 = w1, n2 = w2, n3 = w3;
+        if (s + 1 < KSTEPS) {
+            const uint4 *nx = ws + (size_t)(s + 1) * 3 * 64;
+            n1 = nx[0]; n2 = nx[64]; n3 = nx[128];
+        }
+        acc = mcp_mfma_bf16(w3, xs[s].p1, acc);
+        acc = mcp_mfma_bf16(w1, xs[s].p3, acc);
+        acc = mcp_mfma_bf16(w2, xs[s].p2, acc);
+        acc = mcp_mfma_bf16(w2, xs[s].p1, acc);
+        acc = mcp_mfma_bf16(w1, xs[s].p2, acc);
+        acc = mcp_mfma_bf16(w1, xs[s].p1, acc);
+        __builtin_amdgcn_sched_barrier(MCP_SPLIT_SCHED_MASK);  // nothing moves across: a mask that let VALU/MFMA cross (0xE) produced WRONG results with this compiler (fusion test) and no speed-up
+        w1 = n1; w2 = n2; w3 = n3;
+    }
+    return acc;
+}
+
 // Weight image of one (out x cin) layer, cin a multiple of 32: entry ((t * ksteps + s) * 3 + piece) * 64 + lane holds the 8 bf16
 // W[32t + (lane&31)][32 (s>>1) + chan_of(8 (s&1) + i, lane>>5)], i = 0..7, ksteps = cin / 16.  Writes entries e, e+stride, ...
 __device__ __forceinline__ void mcp_split_weights(uint4 *dst, const float *__restrict__ w, int cin, int out_tiles, int first, int stride) {

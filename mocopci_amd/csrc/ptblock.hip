@@ -8,14 +8,19 @@
 // a chain of v_mfma_f32_32x32x2_f32 whose accumulator tile is the next layer's B operand (as in fusion.hip), gathered
 // k / v rows are loaded directly in accumulator layout, and -- because one point's 16 neighbours of one lane-half are
 // exactly one 16-lane DPP row -- the per-channel softmax and the weighted sum are DPP row reductions.
+// The three 64 -> 64 layers run on the bf16 matrix pipe through the exact three-way operand split of mfma_split.h (weights
+// split once by mcp_ptblock_pack, activations in registers); the K = 4 first layer of fc_delta stays on the f32-input MFMA.
 #include "common.h"
+#include "mfma_split.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int C = 64, KNB = 16, WAVES = 4;
-// packed image (floats): wd1 [2][2][64] | wd2, wg1, wg2 each [2][8][64][4] | bd2, bg1, bg2 each [2][2][16]
-constexpr int OFF_D1 = 0, OFF_D2 = 256, OFF_G1 = OFF_D2 + 4096, OFF_G2 = OFF_G1 + 4096, OFF_BD2 = OFF_G2 + 4096,
+// packed image (floats): wd1 [2][2][64] | wd2, wg1, wg2 each as split pieces [2 tiles][4 k-steps][3 pieces][64 lanes] x uint4
+// | bd2, bg1, bg2 each [2][2][16]
+constexpr int WSPLIT = 2 * 4 * 3 * 64 * 4;  // floats per 64x64 layer
+constexpr int OFF_D1 = 0, OFF_D2 = 256, OFF_G1 = OFF_D2 + WSPLIT, OFF_G2 = OFF_G1 + WSPLIT, OFF_BD2 = OFF_G2 + WSPLIT,
               OFF_BG1 = OFF_BD2 + 64, OFF_BG2 = OFF_BG1 + 64, PACK_FLOATS = OFF_BG2 + 64;
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -48,12 +53,8 @@ __global__ __launch_bounds__(256) void ptblock_pack_kernel(const float *__restri
             const int lane = e & 63, s = (e >> 6) & 1, t = e >> 7;
             const int row = 32 * t + (lane & 31), c = 2 * s + (lane >> 5);
             v = c < 3 ? wd1[row * 3 + c] : bd1[row];
-        } else if (e < OFF_BD2) {  // three 64x64 layers, [t][q][lane][4]
-            const int f = (e - OFF_D2) & 4095, which = (e - OFF_D2) >> 12;
-            const float *w = which == 0 ? wd2 : which == 1 ? wg1 : wg2;
-            const int j = f & 3, lane = (f >> 2) & 63, q = (f >> 8) & 7, t = f >> 11;
-            const int s = 4 * q + j, tin = s >> 4, r = s & 15;
-            v = w[(32 * t + (lane & 31)) * C + 32 * tin + chan_of(r, lane >> 5)];
+        } else if (e < OFF_BD2) {  // three 64x64 layers: written below as split pieces
+            continue;
         } else {  // biases [t][h][r]
             const int f = (e - OFF_BD2) & 63, which = (e - OFF_BD2) >> 6;
             const float *bb = which == 0 ? bd2 : which == 1 ? bg1 : bg2;
@@ -62,26 +63,25 @@ __global__ __launch_bounds__(256) void ptblock_pack_kernel(const float *__restri
         }
         packed[e] = v;
     }
+    const int first = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    mcp_split_weights(reinterpret_cast<uint4 *>(packed + OFF_D2), wd2, C, 2, first, stride);
+    mcp_split_weights(reinterpret_cast<uint4 *>(packed + OFF_G1), wg1, C, 2, first, stride);
+    mcp_split_weights(reinterpret_cast<uint4 *>(packed + OFF_G2), wg2, C, 2, first, stride);
 }
 
 // one 64 -> 64 layer on accumulator-layout input x[2]; bias as the initial accumulator
 __device__ __forceinline__ void layer64(const float *lds, int off_w, int off_b, int lane, int h, const f32x16 (&x)[2], f32x16 (&y)[2],
                                         bool relu) {
-    const float4 *wq = reinterpret_cast<const float4 *>(lds + off_w);
+    const uint4 *ws = reinterpret_cast<const uint4 *>(lds + off_w) + lane;
+    McpSplit3 xs[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xs[s] = mcp_split_kstep(x[s >> 1], s & 1);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = lds[off_b + (t * 2 + h) * 16 + r];
-#pragma unroll
-        for (int q4 = 0; q4 < 8; ++q4) {
-            const float4 w = wq[(t * 8 + q4) * 64 + lane];
-            const int tin = q4 >> 2, r0 = (q4 & 3) * 4;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x[tin][r0 + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x[tin][r0 + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x[tin][r0 + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x[tin][r0 + 3], acc, 0, 0, 0);
-        }
+        acc = mcp_tile_split<4>(ws + (size_t)t * 4 * 3 * 64, xs, acc);
         if (relu) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);

@@ -1,0 +1,63 @@
+"""-m gpu: every fused MFMA kernel run repeatedly on the same inputs must give bit-identical outputs (no atomics, no races).
+Sized like the N=8192 pipeline on purpose: a software-pipelined variant of the fusion kernel was wrong on ~5 of 196608 points
+per launch, only with two waves per SIMD -- invisible at unit-test sizes, caught by the forward determinism test and by this one."""
+import pytest
+import torch
+
+from mocopci_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*s, scale=1.0):
+    return torch.randn(*s, device=DEV) * scale
+
+
+def repeatable(fn, reps=6):
+    ref = fn()
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        out = fn()
+        torch.cuda.synchronize()
+        if not torch.equal(out, ref):
+            return False
+    return True
+
+
+def test_fusion_kernel_is_deterministic():
+    torch.manual_seed(0)
+    be = ops.backend()
+    B, N = 24, 8192
+    p1 = rnd(B, N, 3, scale=20.0)
+    p2 = p1 + rnd(B, N, 3, scale=0.05)
+    idx = torch.randint(0, N, (B, N, 64), device=DEV, dtype=torch.int32)
+    ws = [rnd(64, 4, scale=0.5), rnd(64, scale=0.1), rnd(64, 64, scale=0.125), rnd(64, scale=0.1), rnd(128, 64, scale=0.125), rnd(128, scale=0.1)]
+    assert repeatable(lambda: be.fusion_mlp(p1, p2, idx, *ws))
+
+
+@pytest.mark.parametrize("d,n", [(64, 2048), (128, 512), (256, 256)])
+def test_cross_kernel_is_deterministic(d, n):
+    torch.manual_seed(d)
+    be = ops.backend()
+    B = 48
+    x1, x2, f1, f2 = rnd(B, n, 3, scale=10.0), rnd(B, n, 3, scale=10.0), rnd(B, n, d), rnd(B, n, d)
+    ix = torch.randint(0, n, (B, n, 32), device=DEV, dtype=torch.int32)
+    pk = be.cross_pack(rnd(d, 3, scale=0.3), rnd(d, scale=0.1), rnd(d, d, scale=d ** -0.5), rnd(d, scale=0.1))
+    assert repeatable(lambda: be.cross_volume(x1, x2, f1, f2, ix, pk))
+
+
+def test_ptblock_and_wide_attention_are_deterministic():
+    torch.manual_seed(1)
+    be = ops.backend()
+    n = 2048
+    xyz, qkv = rnd(24, n, 3, scale=10.0), rnd(24, n, 192)
+    ix = torch.randint(0, n, (24, n, 16), device=DEV, dtype=torch.int32)
+    pk = be.ptblock_pack(rnd(64, 3, scale=0.3), rnd(64, scale=0.1), *[t for _ in range(3) for t in (rnd(64, 64, scale=0.125), rnd(64, scale=0.1))])
+    assert repeatable(lambda: be.ptblock_attention(xyz, qkv[..., :64], qkv[..., 64:128], qkv[..., 128:], ix, pk))
+    q, kv = rnd(32, 256, 768), rnd(32, 256, 1536)
+    assert repeatable(lambda: be.attention(q, kv, 3, scale=1 / 16))
+    q, kv = rnd(8, 256, 256), rnd(8, 256, 512)
+    assert repeatable(lambda: be.attention(q, kv, 8))
+    q, kv = rnd(48, 2048, 64), rnd(48, 2048, 128)
+    assert repeatable(lambda: be.attention(q, kv, 8))
