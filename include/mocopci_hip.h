@@ -149,6 +149,13 @@ int mcp_group_rows_add_leaky(int b, int n, int c, int s, int k, float slope, con
  * -> grad_points (B,N,C) += scatter; the caller zero-initialises grad_points. */
 int mcp_group_rows_grad(int b, int n, int c, int t, const float *grad_out, const int *idx, float *grad_points, mcp_stream_t stream);
 
+/* The same gradient as a DETERMINISTIC segmented reduction: the caller sorts the T gather positions of each batch
+ * element by destination row with a stable sort and passes the permutation order (B,T) int32 and the CSR offsets seg (B,N+1)
+ * int32 (seg[b][d] .. seg[b][d+1] = the slice of order[b] that gathers row d).  grad_points (B,N,C) is fully written (rows
+ * nobody gathered are zero), summed in the sorted order: bit-identical from run to run, no atomics. */
+int mcp_group_rows_grad_sorted(int b, int n, int c, int t, const float *grad_out, const int *order, const int *seg,
+                               float *grad_points, mcp_stream_t stream);
+
 /* UpsampleFlow.forward (mocopci.py:1485-1502) / the interpolation half of PointWarping (:1472-1479):
  * dense (B,N,3), sparse (B,S,3), feat (B,S,C) channel-last -> out (B,N,C);
  * 3-NN in expansion form, weights 1/max(||d||,1e-10) normalised.  idx3 (int32) and w3 (B,N,3) are

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_interp3_apply_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_group_rows_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
+    "mcp_group_rows_grad_sorted": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_group_rows_add_leaky": [_i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     "mcp_fusion": [_i, _i, _i] + [_p] * 11,
     "mcp_cross_packed_floats": [_i],

@@ -113,6 +113,41 @@ __global__ __launch_bounds__(BLK) void group_rows_grad_kernel(int n, int c, long
     }
 }
 
+// Deterministic backward of the row gather ("deterministic segmented reduction instead of atomicAdd").  The
+// caller sorts the T gather positions of every batch element by destination row (stable, so equal destinations keep their
+// original order) and passes the permutation `order` (B,T) plus the CSR offsets seg (B,N+1).  One thread per (destination
+// row, channel quad / channel) walks its segment in that fixed order: the same bits on every run, no atomics, no pre-zeroing
+// (rows nobody gathered from are written as zeros).
+template <bool VEC4>
+__global__ __launch_bounds__(BLK) void group_rows_grad_sorted_kernel(int n, int c, int t, long long total, const float *__restrict__ grad_out,
+                                                                     const int *__restrict__ order, const int *__restrict__ seg,
+                                                                     float *__restrict__ grad_points) {
+    const int cw = VEC4 ? c / 4 : c;
+    long long g = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long stride = (long long)gridDim.x * BLK;
+    for (; g < total; g += stride) {
+        const long long row = g / cw;  // b * n + destination
+        const int col = (int)(g - row * cw);
+        const int b = (int)(row / n), d = (int)(row - (long long)b * n);
+        const int *sg = seg + (long long)b * (n + 1) + d;
+        const int lo = sg[0], hi = sg[1];
+        const int *ord = order + (long long)b * t;
+        const float *src = grad_out + (long long)b * t * c;
+        if (VEC4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = lo; j < hi; ++j) {
+                const float4 v = reinterpret_cast<const float4 *>(src + (long long)ord[j] * c)[col];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            reinterpret_cast<float4 *>(grad_points + row * c)[col] = acc;
+        } else {
+            float acc = 0.f;
+            for (int j = lo; j < hi; ++j) acc += src[(long long)ord[j] * c + col];
+            grad_points[row * c + col] = acc;
+        }
+    }
+}
+
 // K4  ball_query_gpu.cu:9-45.  The reference gives one thread per centre a serial scan of all N points with an
 // early break.  Here a WAVE owns a centre: lane l tests points 64*i + l (coalesced reads), the hit mask of each step
 // is a ballot, and a hit's output slot is (hits so far) + (hits in lower lanes) -- exactly the reference's index
@@ -308,6 +343,21 @@ MCP_EXPORT int mcp_group_rows_grad(int b, int n, int c, int t, const float *grad
     const long long total = (long long)b * t * c;
     const unsigned grid = (unsigned)min((long long)mcp_divup((unsigned)min(total, (long long)0x7fffffff), BLK), 8192LL);
     hipLaunchKernelGGL(group_rows_grad_kernel, dim3(grid), dim3(BLK), 0, (hipStream_t)stream, n, c, total, t, grad_out, idx, grad_points);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_group_rows_grad_sorted(int b, int n, int c, int t, const float *grad_out, const int *order, const int *seg,
+                                          float *grad_points, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && c > 0 && t > 0 && grad_out && order && seg && grad_points);
+    const bool vec4 = (c % 4 == 0) && !((((uintptr_t)grad_out) | ((uintptr_t)grad_points)) & 15);
+    const long long total = (long long)b * n * (vec4 ? c / 4 : c);
+    const unsigned grid = (unsigned)min((long long)mcp_divup((unsigned)min(total, (long long)0x7fffffff), BLK), 16384LL);
+    if (vec4)
+        hipLaunchKernelGGL(group_rows_grad_sorted_kernel<true>, dim3(grid), dim3(BLK), 0, (hipStream_t)stream, n, c, t, total, grad_out, order,
+                           seg, grad_points);
+    else
+        hipLaunchKernelGGL(group_rows_grad_sorted_kernel<false>, dim3(grid), dim3(BLK), 0, (hipStream_t)stream, n, c, t, total, grad_out, order,
+                           seg, grad_points);
     return mcp_launch_status();
 }
 

@@ -100,6 +100,7 @@ class MoCoPCI(nn.Module):
             else:
                 node.register_parameter(parts[-1], nn.Parameter(t))
         self._cache = None
+        self._live = None  # training forward: {name: live parameter / buffer}; derived tensors are then rebuilt, not cached
         self.eval()
 
     # ---- parameter access ---------------------------------------------------------------
@@ -112,6 +113,8 @@ class MoCoPCI(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _params(self):
+        if self._live is not None:
+            return self._live
         if self._cache is None:
             c = {}
             for n, p in self.named_parameters():
@@ -121,6 +124,16 @@ class MoCoPCI(nn.Module):
             self._cache = c
             self._time_cache = {}
         return self._cache
+
+    def derived(self, key, fn):
+        """A tensor computed from parameters (folded BatchNorm, packed kernel operands, ...): cached for inference, rebuilt from
+        the live parameters -- so gradients reach them -- in a training forward."""
+        if self._live is not None:
+            return fn()
+        P = self._params()
+        if key not in P:
+            P[key] = fn()
+        return P[key]
 
     def W(self, name):
         """weight of a 1x1 conv / linear as (out,in)."""
@@ -140,11 +153,11 @@ class MoCoPCI(nn.Module):
     def bn_eval(self, x, name, eps):
         """BatchNorm in eval mode on a channel-last tensor: one fused multiply-add with cached (scale, shift)."""
         P = self._params()
-        key = ("bn", name, eps)
-        if key not in P:
+
+        def fold():
             scale = P[name + ".weight"] * torch.rsqrt(P[name + ".running_var"] + eps)
-            P[key] = (scale.contiguous(), (P[name + ".bias"] - P[name + ".running_mean"] * scale).contiguous())
-        scale, shift = P[key]
+            return scale.contiguous(), (P[name + ".bias"] - P[name + ".running_mean"] * scale).contiguous()
+        scale, shift = self.derived(("bn", name, eps), fold)
         return torch.addcmul(shift, x, scale)
 
     # ---- point-set layers ---------------------------------------------------------------
@@ -180,7 +193,7 @@ class MoCoPCI(nn.Module):
         bound), which overlap with the KNN / PointConv work of the main stream.  1: branches that depend only on encoder
         features (see Early).  One set per caller stream, so forwards issued on different streams stay independent.
         CPU backends run inline."""
-        if device.type != "cuda":
+        if device.type != "cuda" or self._live is not None:  # a training forward runs on one stream (autograd replays it in order)
             return None
         key = (device.index, torch.cuda.current_stream(device).stream_id, which)
         sides = self.__dict__.setdefault("_sides", {})
@@ -280,11 +293,10 @@ class MoCoPCI(nn.Module):
         # every cross() MoCoPCI builds has one D -> D mlp layer with D in {64, 128, 256} (pointconv_util.py:735-748)
         assert len(mlp) == 1 and points2.shape[-1] == points1.shape[-1]
         conv = mlp[0] + ".composed_module.0"
-        P = self._params()
-        key = ("cross_pack", be.name, pos, conv)
-        if key not in P:  # the layer's weights in the kernel's operand layout, built once
-            P[key] = be.cross_pack(self.W(pos), self.Bv(pos), self.W(conv), self.Bv(conv))
-        return be.cross_volume(xyz1, xyz2, points1.contiguous(), points2.contiguous(), idx, P[key])
+        w = (self.W(pos), self.Bv(pos), self.W(conv), self.Bv(conv))
+        # the layer's weights in the kernel's operand layout, built once (inference); a training forward packs the live weights
+        packed = None if self._live is not None else self.derived(("cross_pack", be.name, pos, conv), lambda: be.cross_pack(*w))
+        return be.cross_layer(xyz1, xyz2, points1, points2, idx, *w, packed=packed)
 
     def interp(self, dense, sparse, feat, cache=None, key=None):
         """UpsampleFlow (mocopci.py:1485-1502) with search reuse on a keyed (dense, sparse) pair."""
@@ -331,12 +343,10 @@ class MoCoPCI(nn.Module):
     def folded_tail(self, fc2, mapping):
         """mapping(fc2(h)) as ONE affine map: W = Wmap Wfc2, b = Wmap bfc2 + bmap (cached).  Used where only the 3-channel
         flow is read downstream and the block's feature output is not (inference)."""
-        P = self._params()
-        key = ("tail", fc2, mapping)
-        if key not in P:
+        def fold():
             wm, bm = self.W(mapping), self.Bv(mapping)
-            P[key] = ((wm @ self.W(fc2)).contiguous(), (wm @ self.Bv(fc2) + bm).contiguous())
-        return P[key]
+            return (wm @ self.W(fc2)).contiguous(), (wm @ self.Bv(fc2) + bm).contiguous()
+        return self.derived(("tail", fc2, mapping), fold)
 
     def cross_frame_att(self, prefix, x, feats=True):
         """Cross_Frame_Att.forward (mocopci.py:499-522) batched over samples.  x (B,2,N,C) holds the two
@@ -348,12 +358,11 @@ class MoCoPCI(nn.Module):
         xr = torch.flip(xn, dims=[1])
         a = prefix + ".attn_feats"
         # head slot 0 is the dropped one and nothing after the attention mixes slots: project only heads 1..3
-        key = ("cfa_heads", prefix)
-        if key not in P:
+        def heads():
             wq, bq, wkv, bkv = self.W(a + ".q"), self.Bv(a + ".q"), self.W(a + ".kv"), self.Bv(a + ".kv")
             sl = lambda t: None if t is None else torch.cat([t[C:4 * C], t[5 * C:8 * C]], dim=0).contiguous()
-            P[key] = (wq[C:].contiguous(), None if bq is None else bq[C:].contiguous(), sl(wkv), sl(bkv))
-        wq, bq, wkv, bkv = P[key]
+            return wq[C:].contiguous(), None if bq is None else bq[C:].contiguous(), sl(wkv), sl(bkv)
+        wq, bq, wkv, bkv = self.derived(("cfa_heads", prefix), heads)
         o = ops.backend().attention(F.linear(xn, wq, bq).reshape(B * Fr, N, 3 * C), F.linear(xr, wkv, bkv).reshape(B * Fr, N, 6 * C), 3,
                                     scale=C ** -0.5)                              # (B*2,N,3C): 3 head slots, each C wide
         o = self.lin(o.reshape(B, Fr, N, 3, C).sum(dim=1).transpose(1, 2), a + ".proj")   # (B,3,N,C)
@@ -369,12 +378,11 @@ class MoCoPCI(nn.Module):
         """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2.  The depthwise k=1 conv is a
         per-channel scale + bias, folded into fc1 once: (W x + b) * s + t = (s W) x + (s b + t)."""
         P = self._params()
-        key = ("mlp_t_fc1", prefix)
-        if key not in P:
+        def fold():
             sc = P[prefix + ".dwconv.dwconv.weight"].reshape(-1)
-            P[key] = ((self.W(prefix + ".fc1") * sc[:, None]).contiguous(),
-                      (self.Bv(prefix + ".fc1") * sc + P[prefix + ".dwconv.dwconv.bias"]).contiguous())
-        w1, b1 = P[key]
+            return ((self.W(prefix + ".fc1") * sc[:, None]).contiguous(),
+                    (self.Bv(prefix + ".fc1") * sc + P[prefix + ".dwconv.dwconv.bias"]).contiguous())
+        w1, b1 = self.derived(("mlp_t_fc1", prefix), fold)
         hid = F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"])
         if tail is not None:
             return F.linear(hid, *self.folded_tail(prefix + ".fc2", tail))
@@ -430,6 +438,7 @@ class MoCoPCI(nn.Module):
     def time_code(self, ts, dim, device):
         """Multiframe_Attention.time_embedding (mocopci.py:172-180): float64 python math, stored fp32."""
         key = (tuple(ts), dim, str(device))
+        self.__dict__.setdefault("_time_cache", {})
         if key not in self._time_cache:
             enc = torch.zeros(len(ts), dim)
             for i, t in enumerate(ts):
@@ -501,12 +510,10 @@ class MoCoPCI(nn.Module):
         """TransformerBlock's x = fc1(features); q, k, v = w_qs(x), w_ks(x), w_vs(x) (pointT_layer2.py:62-66; the three
         projections have no bias and nothing else reads x) as ONE (C -> 3C) affine map: W = [Wq; Wk; Wv] W1, b = [..] b1.
         Returns the packed (B,N,3C) tensor [q | k | v]."""
-        P = self._params()
-        key = ("qkv_fold", prefix)
-        if key not in P:
+        def fold():
             w3 = torch.cat([self.W(prefix + w) for w in (".w_qs", ".w_ks", ".w_vs")], dim=0)
-            P[key] = ((w3 @ self.W(prefix + ".fc1")).contiguous(), (w3 @ self.Bv(prefix + ".fc1")).contiguous())
-        return F.linear(feats, *P[key])
+            return (w3 @ self.W(prefix + ".fc1")).contiguous(), (w3 @ self.Bv(prefix + ".fc1")).contiguous()
+        return F.linear(feats, *self.derived(("qkv_fold", prefix), fold))
 
     def transformer_block(self, prefix, feats, xyz, k=16, qkv=None):
         """TransformerBlock.forward (pointT_layer2.py:58-77): vector attention over the 16 nearest
@@ -517,23 +524,19 @@ class MoCoPCI(nn.Module):
         if qkv is None:
             qkv = self.qkv_projection(prefix, feats)
         C = feats.shape[-1]
-        P = self._params()
-        key = ("ptblock_pack", be.name, prefix)
-        if key not in P:
-            P[key] = be.ptblock_pack(self.W(prefix + ".fc_delta.0"), self.Bv(prefix + ".fc_delta.0"), self.W(prefix + ".fc_delta.2"),
-                                     self.Bv(prefix + ".fc_delta.2"), self.W(prefix + ".fc_gamma.0"), self.Bv(prefix + ".fc_gamma.0"),
-                                     self.W(prefix + ".fc_gamma.2"), self.Bv(prefix + ".fc_gamma.2"))
-        res = be.ptblock_attention(xyz, qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], idx, P[key])
+        w = [t for n in (".fc_delta.0", ".fc_delta.2", ".fc_gamma.0", ".fc_gamma.2") for t in (self.W(prefix + n), self.Bv(prefix + n))]
+        packed = None if self._live is not None else self.derived(("ptblock_pack", be.name, prefix), lambda: be.ptblock_pack(*w))
+        res = be.ptblock_layer(xyz, qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], idx, w, packed=packed)
         return self.lin(res, prefix + ".fc2") + feats
 
     def folded_conv_bn(self, conv, bn, eps):
         """1x1 conv followed by eval-mode BatchNorm as one affine map (cached)."""
-        key = ("fold", conv, bn)
         P = self._params()
-        if key not in P:
+
+        def fold():
             scale = P[bn + ".weight"] * torch.rsqrt(P[bn + ".running_var"] + eps)
-            P[key] = ((self.W(conv) * scale[:, None]).contiguous(), ((self.Bv(conv) - P[bn + ".running_mean"]) * scale + P[bn + ".bias"]).contiguous())
-        return P[key]
+            return (self.W(conv) * scale[:, None]).contiguous(), ((self.Bv(conv) - P[bn + ".running_mean"]) * scale + P[bn + ".bias"]).contiguous()
+        return self.derived(("fold", conv, bn), fold)
 
     def fusion(self, p1, p2, k=32, idx_self=None):
         """MultiFrameEstimatier.knn_group + fusion (mocopci.py:798-819).  p1, p2 (B,N,3)."""
@@ -546,9 +549,11 @@ class MoCoPCI(nn.Module):
         return be.fusion_mlp(p1, p2.contiguous(), idx, *wb)
 
     # ---- decoder ------------------------------------------------------------------------
-    def run_decoder(self, pcs, feats, B):
+    def run_decoder(self, pcs, feats, B, train=False):
         """MultiFrameEstimatier.forward (mocopci.py:821-1059).  pcs/feats hold both frames stacked on
-        the batch axis (frame 1 = [:B], frame 2 = [B:]).  Returns out_lst: 3 x (B,N,3)."""
+        the batch axis (frame 1 = [:B], frame 2 = [B:]).  Returns out_lst: 3 x (B,N,3); with train=True
+        (flows_lst_f, flows_lst_b, out_lst) as the reference does (mocopci.py:1056-1059), every (direction, frame) flow of every
+        level being computed then (the training loss reads them all)."""
         m = "multi_frame_inference."
         dev = pcs[0].device
         sw = lambda t: torch.cat([t[B:], t[:B]], dim=0)                            # swap the two frames
@@ -582,7 +587,7 @@ class MoCoPCI(nn.Module):
         # Which level-1 flows are read: l0 (below) uses, of the 2B samples x 3 frames, the forward branch's frames 0,1 and
         # the backward branch's frame 0.  (Their flow embeddings also need each frame's attention partner f <-> 2-f, so
         # only (backward, frame 1) is dead at level 1; the same selection one level up measured no gain and is not made.)
-        rows1 = [3 * i for i in range(B)] + [3 * i + 1 for i in range(B)] + [3 * (i + B) for i in range(B)]
+        rows1 = None if train else [3 * i for i in range(B)] + [3 * i + 1 for i in range(B)] + [3 * (i + B) for i in range(B)]
 
         # l2 (mocopci.py:870-911): rows [:B] = forward direction, rows [B:] = backward direction
         ups = self.interp_flows(pcs[2], pcs[3], frame3s, cache, "32")
@@ -607,15 +612,25 @@ class MoCoPCI(nn.Module):
         # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).  Of the level-1 flows
         # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.
         fus[1] = early.get(("fus", 1))
-        flow_src = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
-                                             feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=early.get(("cos", 1)))[0].contiguous()  # (3B,N1,3)
+        frame1s = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
+                                            feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=early.get(("cos", 1)))[0].contiguous()
         pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
         f0 = torch.cat([feats[0][:B], feats[0][:B], feats[0][B:]], dim=0)
         # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
         # (2B rows), its rows repeated for the 3B arrangement
         i3, w3 = early.get("i3_01")
         rep3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
-        up_flow = ops.backend().interp3_apply(flow_src, rep3(i3), rep3(w3))        # (3B,N,3)
+        if train:
+            # all six upsampled level-1 flows (mocopci.py:1011-1019): up_f[i] = upsample(frame1s_f[:, i]) on frame 1's points,
+            # up_b[i] = upsample(frame1s_b[:, 2 - i]) on frame 2's points
+            src6 = torch.cat([frame1s[:B, 0], frame1s[:B, 1], frame1s[:B, 2], frame1s[B:, 2], frame1s[B:, 1], frame1s[B:, 0]], dim=0)
+            rep6 = lambda t: torch.cat([t[:B]] * 3 + [t[B:]] * 3, dim=0)
+            up6 = ops.backend().interp3_apply(src6.contiguous(), rep6(i3), rep6(w3))  # (6B,N,3)
+            up_f, up_b = list(up6[:3 * B].split(B)), list(up6[3 * B:].split(B))
+            up_flow = torch.cat([up_f[0], up_f[1], up_b[2]], dim=0)
+        else:
+            flow_src = frame1s                                                     # (3B,N1,3): the three flows read below
+            up_flow = ops.backend().interp3_apply(flow_src, rep3(i3), rep3(w3))    # (3B,N,3)
         warped = pc0 + up_flow
         # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022)
         wf = f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev)
@@ -653,15 +668,48 @@ class MoCoPCI(nn.Module):
             upf = ops.backend().interp3(warped, down, shape)
         refine = self.lin(F.relu(self.lin(upf, m + "pred.0")), m + "pred.2")       # (3B,N,3)
         final = self.fusion(warped, refine, idx_self=idx_self)
-        return [final[:B], final[B:2 * B], final[2 * B:]]
+        out_lst = [final[:B], final[B:2 * B], final[2 * B:]]
+        if not train:
+            return out_lst
+        # the lists the training loss reads (mocopci.py:1011-1059), all (B,n,3): index i = interpolated frame
+        p1, p2 = [p[:B] for p in pcs], [p[B:] for p in pcs]
+        lv = {1: frame1s, 2: frame2s, 3: frame3s}                                  # (2B,3,N_l,3): [:B] forward, [B:] backward
+        flows_f = [[p1[0] + up_f[i] for i in range(3)], [p1[0] + up_b[2 - i] for i in range(3)]]
+        flows_b = [[p2[0] + up_b[i] for i in range(3)], [p2[0] + up_f[2 - i] for i in range(3)]]
+        for l in (1, 2, 3):
+            flows_f.append([p1[l] + lv[l][:B, i] for i in range(3)])
+            flows_b.append([p2[l] + lv[l][B:, 2 - i] for i in range(3)])
+        return flows_f, flows_b, out_lst
 
     def forward(self, xyz1, xyz2, gt=None, t=None, train=False):
-        """MoCoPCI.forward (mocopci.py:1069-1097): xyz1, xyz2 (B,3,N) -> out_lst, 3 x (B,N,3)."""
-        if train:
-            raise NotImplementedError("inference graph only (train=True needs the backward kernels: SURVEY 8(f) #3)")
+        """MoCoPCI.forward (mocopci.py:1069-1097): xyz1, xyz2 (B,3,N) -> out_lst, 3 x (B,N,3).
+        train=True: (frames_lst_f, frames_lst_b, gt_frame, out_lst) as the reference returns, computed with autograd enabled so
+        that train.py:135-160's loss can be back-propagated: gradients reach every parameter through the fused kernels
+        (mocopci_amd.grad).  gt: 3 x (B,3,N) as train.py:125-126 passes it.  Normalisation layers use their running statistics
+        and dropout / stochastic depth are not applied in either mode (the reference's nn.Dropout(0.05) / DropPath(0.04) draw from
+        the device RNG and cannot be pinned; a fine-tuning run from a checkpoint behaves like the reference's net.eval() graph)."""
         B = xyz1.shape[0]
         xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
-        with torch.no_grad(), ops.backend().cloud_scope():
-            self._early = Early(self, xyz.device)
-            pcs, feats = self.run_encoder(xyz, self._early)
-            return self.run_decoder(pcs, feats, B)
+        if not train:
+            with torch.no_grad(), ops.backend().cloud_scope():
+                self._early = Early(self, xyz.device)
+                pcs, feats = self.run_encoder(xyz, self._early)
+                return self.run_decoder(pcs, feats, B)
+        self._live = {**dict(self.named_parameters()), **dict(self.named_buffers())}
+        try:
+            with torch.enable_grad(), ops.backend().cloud_scope():
+                self._early = Early(self, xyz.device)
+                pcs, feats = self.run_encoder(xyz, self._early)
+                flows_f, flows_b, out_lst = self.run_decoder(pcs, feats, B, train=True)
+        finally:
+            self._live = None
+        N = xyz1.shape[2]
+        gt_frame = []
+        if gt is not None:
+            with torch.no_grad():
+                for g in gt:                                                       # downsampling(), mocopci.py:1099-1104
+                    gcl = g.transpose(1, 2).contiguous()
+                    gt_frame.append([g] + [self.fps_gather(gcl, N // d).transpose(1, 2).contiguous() for d in (4, 16, 32)])
+        frames_lst_f = [[lst[i] for lst in flows_f] for i in range(3)]
+        frames_lst_b = [[lst[i] for lst in flows_b] for i in range(3)]
+        return frames_lst_f, frames_lst_b, gt_frame, out_lst

@@ -18,7 +18,7 @@ import threading
 
 import torch
 
-from . import _lib
+from . import _lib, grad
 
 MCP_DIST_EXPANSION = 0
 MCP_DIST_DIRECT = 1
@@ -59,33 +59,18 @@ class _GroupRowsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        """Deterministic segmented reduction: stable sort of the gather positions by destination row, in-order sums per row."""
         (idx,) = ctx.saved_tensors
         B, C = grad_out.shape[0], grad_out.shape[-1]
-        T = idx[0].numel()
+        T, N = idx[0].numel(), ctx.n
         grad_out = grad_out.contiguous()
-        grad = torch.zeros((B, ctx.n, C), dtype=torch.float32, device=grad_out.device)
-        _call("mcp_group_rows_grad", grad_out, B, ctx.n, C, T, _lib.fptr(grad_out), _lib.iptr(idx), _lib.fptr(grad))
+        keys, order = torch.sort(idx.reshape(B, T), dim=1, stable=True)
+        bounds = torch.arange(N + 1, device=idx.device, dtype=keys.dtype).expand(B, N + 1).contiguous()
+        seg = torch.searchsorted(keys.contiguous(), bounds).int()
+        grad = torch.empty((B, N, C), dtype=torch.float32, device=grad_out.device)
+        _call("mcp_group_rows_grad_sorted", grad_out, B, N, C, T, _lib.fptr(grad_out), _lib.iptr(order.int().contiguous()), _lib.iptr(seg.contiguous()),
+              _lib.fptr(grad))
         return grad, None
-
-
-class _Interp3ApplyFn(torch.autograd.Function):
-    """Three-neighbour blend with its backward w.r.t. the sparse features (counterpart of ThreeInterpolate, pointnet2_utils.py:108-153)."""
-
-    @staticmethod
-    def forward(ctx, feat, idx3, w3):
-        idx3, w3 = idx3.contiguous(), w3.contiguous()
-        ctx.save_for_backward(idx3, w3)
-        ctx.s = feat.shape[1]
-        return _interp3_apply_fwd(feat.contiguous(), idx3, w3)
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        idx3, w3 = ctx.saved_tensors
-        B, N, C = grad_out.shape
-        grad_out = grad_out.contiguous()
-        grad = torch.zeros((B, ctx.s, C), dtype=torch.float32, device=grad_out.device)
-        _call("mcp_interp3_apply_grad", grad_out, B, N, ctx.s, C, _lib.fptr(grad_out), _lib.iptr(idx3), _lib.fptr(w3), _lib.fptr(grad))
-        return grad, None, None
 
 
 class HipBackend:
@@ -93,6 +78,7 @@ class HipBackend:
 
     def fps(self, xyz, npoint):
         """furthest_point_sample (pointnet2_utils.py:10-29): xyz (B,N,3) -> (B,npoint) int32."""
+        xyz = xyz.detach()
         B, N, _ = xyz.shape
         out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
@@ -172,6 +158,7 @@ class HipBackend:
     def knn(self, query, ref, k, mode=MCP_DIST_EXPANSION, return_dist=False):
         """knn_point(k, ref, query) (mocopci.py:1158-1169): (B,Q,3),(B,N,3) -> (B,Q,k) int32,
         ascending by (distance, index)."""
+        query, ref = query.detach(), ref.detach()  # an index-producing search: no gradient (pointnet2_utils.py:31-33)
         B, Q, _ = query.shape
         N = ref.shape[1]
         idx = torch.empty((B, Q, k), dtype=torch.int32, device=query.device)
@@ -201,6 +188,7 @@ class HipBackend:
     def knn_cosine(self, qfeat, rfeat, k, return_dist=False):
         """knn_point_cosine(k, rfeat, qfeat) (pointconv_util.py:111-153) on channel-last features:
         (B,Q,C),(B,N,C) -> (B,Q,k) int32, ascending by (1 - cosine, index).  MFMA kernel, C in {64,128,256}."""
+        qfeat, rfeat = qfeat.detach().contiguous(), rfeat.detach().contiguous()
         B, Q, C = qfeat.shape
         N = rfeat.shape[1]
         idx = torch.empty((B, Q, k), dtype=torch.int32, device=qfeat.device)
@@ -212,10 +200,10 @@ class HipBackend:
 
     def group_rows(self, points, idx):
         """index_points_group / index_points_gather (mocopci.py:1190-1215): points (B,N,C),
-        idx (B,...) int32 -> (B,...,C).  Differentiable w.r.t. points (scatter-add backward kernel)."""
+        idx (B,...) int32 -> (B,...,C).  Differentiable w.r.t. points (deterministic segmented-reduction backward)."""
         if points.requires_grad and torch.is_grad_enabled():
             return _GroupRowsFn.apply(points, idx)
-        return _group_rows_fwd(points, idx)
+        return _group_rows_fwd(points.contiguous(), idx)
 
     def group_rows_add_leaky(self, points, idx, centre, slope=0.1):
         """leaky(points[idx] + centre[:, :, None, :]): points (B,N,C), idx (B,S,K), centre (B,S,C) -> (B,S,K,C)
@@ -227,28 +215,32 @@ class HipBackend:
               _lib.fptr(centre), _lib.fptr(out))
         return out
 
-    def interp3_search(self, dense, sparse):
-        """3-NN search + inverse-distance weights of UpsampleFlow (mocopci.py:1494-1498)."""
+    def _interp3_weights(self, dense, sparse, idx3):
         B, N, _ = dense.shape
-        S = sparse.shape[1]
-        idx3 = self.knn(dense, sparse, 3)  # spatially pruned for the large levels, exhaustive below
         w3 = torch.empty((B, N, 3), dtype=torch.float32, device=dense.device)
-        _call("mcp_interp3_weights", dense, B, N, S, _lib.fptr(dense), _lib.fptr(sparse), _lib.iptr(idx3), _lib.fptr(w3))
+        _call("mcp_interp3_weights", dense, B, N, sparse.shape[1], _lib.fptr(dense), _lib.fptr(sparse), _lib.iptr(idx3), _lib.fptr(w3))
+        return w3
+
+    def interp3_search(self, dense, sparse):
+        """3-NN search + inverse-distance weights of UpsampleFlow (mocopci.py:1494-1498).  The weights are differentiable
+        w.r.t. both coordinate sets (the reference's are: warped coordinates depend on predicted flows)."""
+        dense, sparse = dense.contiguous(), sparse.contiguous()
+        idx3 = self.knn(dense.detach(), sparse.detach(), 3)  # spatially pruned for the large levels, exhaustive below
+        w3 = grad.run(self._interp3_weights, lambda d, s_, i: grad.interp3_weights_twin(self.group_rows, d, s_, i), dense, sparse, idx3)
         return idx3, w3
 
     def interp3_apply(self, feat, idx3, w3):
-        """Blend of the three neighbours' rows; differentiable w.r.t. feat (scatter-add backward kernel)."""
-        if feat.requires_grad and torch.is_grad_enabled():
-            return _Interp3ApplyFn.apply(feat, idx3, w3)
-        return _interp3_apply_fwd(feat, idx3, w3)
+        """Blend of the three neighbours' rows; differentiable w.r.t. feat and the weights."""
+        return grad.run(lambda f, i, w: _interp3_apply_fwd(f.contiguous(), i.contiguous(), w.contiguous()),
+                        lambda f, i, w: grad.interp3_apply_twin(self.group_rows, f, i, w), feat, idx3, w3)
 
     def interp3(self, dense, sparse, feat):
         """UpsampleFlow.forward (mocopci.py:1485-1502): dense (B,N,3), sparse (B,S,3), feat (B,S,C) -> (B,N,C)."""
         B, N, _ = dense.shape
         S, C = feat.shape[1], feat.shape[2]
-        # large levels: spatially pruned 3-NN search.  The same two-step route carries the gradient w.r.t. feat (the fused
-        # small-level kernel below has no autograd node), so it is also taken whenever a gradient is wanted.
-        if (S >= self.PRUNE_MIN_REFS and N >= self.PRUNE_MIN_QUERIES) or (feat.requires_grad and torch.is_grad_enabled()):
+        # large levels: spatially pruned 3-NN search.  The same two-step route carries the gradients (the fused small-level
+        # kernel below has no autograd node), so it is also taken whenever one is wanted.
+        if (S >= self.PRUNE_MIN_REFS and N >= self.PRUNE_MIN_QUERIES) or grad.wants_grad(dense, sparse, feat):
             idx3, w3 = self.interp3_search(dense, sparse)
             return self.interp3_apply(feat, idx3, w3)
         idx3 = torch.empty((B, N, 3), dtype=torch.int32, device=dense.device)
@@ -259,7 +251,11 @@ class HipBackend:
         return out
 
     def fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
-        """fusion after the neighbour searches (mocopci.py:803-819), BN folded into (w,b): -> (B,N,3)."""
+        """fusion after the neighbour searches (mocopci.py:803-819), BN folded into (w,b): -> (B,N,3).  Differentiable."""
+        return grad.run(self._fusion_mlp, lambda *a: grad.fusion_twin(self.group_rows, *a), p1, p2, idx, w1, b1, w2, b2, w3, b3)
+
+    def _fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
+        p1, p2, w1, b1, w2, b2, w3, b3 = (t.contiguous() for t in (p1, p2, w1, b1, w2, b2, w3, b3))
         B, N, _ = p1.shape
         out = torch.empty((B, N, 3), dtype=torch.float32, device=p1.device)
         _call("mcp_fusion", p1, B, N, idx.shape[-1], _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(idx), _lib.fptr(w1), _lib.fptr(b1),
@@ -288,6 +284,21 @@ class HipBackend:
               _lib.fptr(points2), _lib.iptr(idx), _lib.fptr(packed), _lib.fptr(out))
         return out
 
+    def cross_layer(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, packed=None):
+        """cross() from the layer's own weights; differentiable w.r.t. coordinates, features and weights.  packed: the
+        cross_pack image of these weights when the caller keeps one (inference); built on the fly otherwise."""
+        def fused(x1, x2, f1, f2, i, wp, bp, wm, bm):
+            pk = packed if packed is not None else self.cross_pack(wp, bp, wm, bm)
+            return self.cross_volume(x1.contiguous(), x2.contiguous(), f1.contiguous(), f2.contiguous(), i, pk)
+        return grad.run(fused, lambda *a: grad.cross_twin(self.group_rows, *a), xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp)
+
+    def ptblock_layer(self, xyz, q, k, v, idx, weights, packed=None):
+        """TransformerBlock vector attention from the block's own weights (wd1,bd1,wd2,bd2,wg1,bg1,wg2,bg2); differentiable."""
+        def fused(x, q_, k_, v_, i, *w):
+            pk = packed if packed is not None else self.ptblock_pack(*w)
+            return self.ptblock_attention(x.contiguous(), q_, k_, v_, i, pk)
+        return grad.run(fused, lambda *a: grad.ptblock_twin(self.group_rows, *a), xyz, q, k, v, idx, *weights)
+
     def ptblock_pack(self, wd1, bd1, wd2, bd2, wg1, bg1, wg2, bg2):
         """Pack fc_delta / fc_gamma of a TransformerBlock (pointT_layer2.py:42-51) into the kernel's operand image."""
         packed = torch.empty((_lib.load().mcp_ptblock_packed_floats(),), dtype=torch.float32, device=wd2.device)
@@ -309,7 +320,12 @@ class HipBackend:
         return out
 
     def pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
-        """PointConv grouping + WeightNet + aggregation (mocopci.py:1330-1335): -> (B,S,(3+D)*8)."""
+        """PointConv grouping + WeightNet + aggregation (mocopci.py:1330-1335): -> (B,S,(3+D)*8).  Differentiable."""
+        return grad.run(self._pointconv_agg, lambda *a: grad.pointconv_agg_twin(self.group_rows, *a), s_xyz, new_xyz, s_points, idx,
+                        w0, b0, w1, b1, w2, b2)
+
+    def _pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
+        s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2 = (t.contiguous() for t in (s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2))
         B, N, D = s_points.shape
         S = new_xyz.shape[1]
         out = torch.empty((B, S, (D + 3) * 8), dtype=torch.float32, device=s_points.device)
@@ -325,7 +341,12 @@ class HipBackend:
         hd = C // heads
         if scale is None:
             scale = hd ** -0.5
-        _lib.fptr(q), _lib.fptr(kv)
+        return grad.run(self._attention, grad.attention_twin, q, kv, heads, float(scale))
+
+    def _attention(self, q, kv, heads, scale):
+        q, kv = q.contiguous(), kv.contiguous()
+        BF, Nq, C = q.shape
+        Nk, hd = kv.shape[1], C // heads
         out = torch.empty((BF, Nq, C), dtype=torch.float32, device=q.device)
         # head dims 8/16: S on MFMA, P.V on packed FMAs; 32/64/256 (ei3, Cross_Frame_Att): both products on MFMA
         name = "mcp_attention_small" if hd in (8, 16) else "mcp_attention_wide"
@@ -334,7 +355,14 @@ class HipBackend:
         return out
 
     def chamfer(self, x, y):
-        """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor."""
+        """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor.  As a training loss
+        (train.py:135-160) it is differentiable w.r.t. both clouds: the nearest neighbours come from the search kernel and the
+        squared distances to them are re-evaluated differentiably."""
+        if grad.wants_grad(x, y):
+            x, y = x.contiguous(), y.contiguous()
+            ixy = self.knn(x.detach(), y.detach(), 1, mode=MCP_DIST_DIRECT)[..., 0].contiguous()
+            iyx = self.knn(y.detach(), x.detach(), 1, mode=MCP_DIST_DIRECT)[..., 0].contiguous()
+            return grad.chamfer_twin(self.group_rows, x, y, ixy, iyx)
         B, N, _ = x.shape
         M = y.shape[1]
         dxy = torch.empty((B, N), dtype=torch.float32, device=x.device)

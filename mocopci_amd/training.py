@@ -1,0 +1,37 @@
+"""The reference's training objective (train.py:135-160) on the outputs of MoCoPCI.forward(train=True)."""
+from . import ops
+
+ALPHA = (1.0, 0.8, 0.4, 0.2)  # train.py:138
+
+
+def chamfer_loss(pred, gt):
+    """models/utils.py:36-45 on the layouts train.py uses: pred (B,n,3) (the reference permutes its (B,n,3) frame to (B,3,n) and
+    chamfer_loss permutes it back), gt (B,3,n)."""
+    return ops.backend().chamfer(pred.contiguous(), gt.transpose(1, 2).contiguous())
+
+
+def multiscale_loss(frames_lst_f, frames_lst_b, gt_frame, out_lst, gt):
+    """losssum of train.py:135-160: final frames vs gt, the two full-resolution warps of both directions, and the level 1..3
+    frames against the FPS-downsampled ground truth with weights alpha[1:]."""
+    loss_f = sum(chamfer_loss(frames, g) for frames, g in zip(out_lst, gt))
+    loss_s_f = loss_s_b = loss_m_f = loss_m_b = 0.0
+    for frames_f, frames_b, gts in zip(frames_lst_f, frames_lst_b, gt_frame):
+        loss_s_f = loss_s_f + 0.5 * chamfer_loss(frames_f[0], gts[0]) + 0.5 * chamfer_loss(frames_f[1], gts[0])
+        loss_s_b = loss_s_b + 0.5 * chamfer_loss(frames_b[0], gts[0]) + 0.5 * chamfer_loss(frames_b[1], gts[0])
+        for l in range(len(ALPHA) - 1):
+            loss_m_f = loss_m_f + ALPHA[l + 1] * chamfer_loss(frames_f[l + 2], gts[l + 1])
+            loss_m_b = loss_m_b + ALPHA[l + 1] * chamfer_loss(frames_b[l + 2], gts[l + 1])
+    total = loss_f + (loss_s_f + loss_s_b) / 2 + 0.25 * loss_m_b + 0.25 * loss_m_f
+    return total, {"final": loss_f, "straight_f": loss_s_f, "straight_b": loss_s_b, "multi_f": loss_m_f, "multi_b": loss_m_b}
+
+
+def train_step(net, optimizer, xyz1, xyz2, gt, clip=2.0):
+    """One iteration of train.py:123-167: forward, loss, backward, gradient-norm clipping at 2.0, optimizer step."""
+    import torch
+    frames_f, frames_b, gt_frame, out_lst = net(xyz1, xyz2, gt, None, True)
+    loss, parts = multiscale_loss(frames_f, frames_b, gt_frame, out_lst, gt)
+    optimizer.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(net.parameters(), clip)
+    optimizer.step()
+    return float(loss), {k: float(v) for k, v in parts.items()}

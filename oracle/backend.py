@@ -15,22 +15,30 @@ class OracleBackend:
         return contextlib.nullcontext()
 
     def fps(self, xyz, npoint):
-        return orc.furthest_point_sample(xyz, npoint)
+        return orc.furthest_point_sample(xyz.detach(), npoint)
 
     def knn(self, query, ref, k, mode=0, return_dist=False):
-        return orc.knn(query, ref, k, mode=mode, return_dist=return_dist)
+        return orc.knn(query.detach(), ref.detach(), k, mode=mode, return_dist=return_dist)
 
     def knn_cosine(self, qfeat, rfeat, k, return_dist=False):
-        return orc.knn_cosine(qfeat, rfeat, k, return_dist=return_dist)
+        return orc.knn_cosine(qfeat.detach(), rfeat.detach(), k, return_dist=return_dist)
 
     def group_rows(self, points, idx):
+        """Row gather; differentiable (plain torch indexing) when a gradient is wanted, the C restatement otherwise."""
+        if points.requires_grad and torch.is_grad_enabled():
+            B = points.shape[0]
+            bidx = torch.arange(B).view(B, *([1] * (idx.dim() - 1)))
+            return points[bidx, idx.long()]
         return orc.group_rows(points, idx.int())
 
     def group_rows_add_leaky(self, points, idx, centre, slope=0.1):
-        return torch.nn.functional.leaky_relu(orc.group_rows(points, idx.int()) + centre.unsqueeze(2), slope)
+        return torch.nn.functional.leaky_relu(self.group_rows(points, idx) + centre.unsqueeze(2), slope)
 
     def interp3_search(self, dense, sparse):
-        idx3 = orc.knn(dense, sparse, 3, mode=0)
+        idx3 = orc.knn(dense.detach(), sparse.detach(), 3, mode=0)
+        if torch.is_grad_enabled() and (dense.requires_grad or sparse.requires_grad):  # mocopci.py:1495-1498, differentiable
+            dist = torch.norm(self.group_rows(sparse, idx3) - dense.unsqueeze(2), dim=3).clamp(min=1e-10)
+            return idx3, (1.0 / dist) / torch.sum(1.0 / dist, dim=2, keepdim=True)
         B, N, _ = dense.shape
         w3 = torch.empty(B, N, 3, dtype=torch.float32)
         orc.lib().orc_interp3_weights(orc._f(dense.contiguous()), orc._f(sparse.contiguous()), orc._i(idx3), orc._f(w3), B, N,
@@ -38,6 +46,8 @@ class OracleBackend:
         return idx3, w3
 
     def interp3_apply(self, feat, idx3, w3):
+        if torch.is_grad_enabled() and (feat.requires_grad or w3.requires_grad):
+            return torch.sum(w3.unsqueeze(-1) * self.group_rows(feat, idx3), dim=2)
         B, N, _ = idx3.shape
         S, C = feat.shape[1], feat.shape[2]
         out = torch.empty(B, N, C, dtype=torch.float32)
@@ -46,11 +56,13 @@ class OracleBackend:
         return out
 
     def interp3(self, dense, sparse, feat):
+        if torch.is_grad_enabled() and (dense.requires_grad or sparse.requires_grad or feat.requires_grad):
+            return self.interp3_apply(feat, *self.interp3_search(dense, sparse))
         return orc.interp3(dense, sparse, feat)
 
     def fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
         """Unfused restatement of mocopci.py:803-819 with BN already folded into (w,b)."""
-        nb = orc.group_rows(p2, idx.int())
+        nb = self.group_rows(p2, idx)
         resi = nb - p1.unsqueeze(2)
         x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)
         for w, b in ((w1, b1), (w2, b2), (w3, b3)):
@@ -65,8 +77,8 @@ class OracleBackend:
         """Unfused restatement of pointconv_util.py:765-781 (one mlp layer)."""
         wpos, bpos, wmlp, bmlp = packed
         F = torch.nn.functional
-        direction = orc.group_rows(xyz2, idx.int()) - xyz1.unsqueeze(2)
-        g2 = orc.group_rows(points2, idx.int())
+        direction = self.group_rows(xyz2, idx) - xyz1.unsqueeze(2)
+        g2 = self.group_rows(points2, idx)
         x = F.leaky_relu((g2 + points1.unsqueeze(2)) + F.linear(direction, wpos, bpos), 0.1)
         x = F.leaky_relu(F.linear(x, wmlp, bmlp), 0.1)
         return x.max(dim=2)[0]
@@ -74,12 +86,18 @@ class OracleBackend:
     def ptblock_pack(self, *weights):
         return weights
 
+    def cross_layer(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, packed=None):
+        return self.cross_volume(xyz1, xyz2, points1, points2, idx, (wpos, bpos, wmlp, bmlp))
+
+    def ptblock_layer(self, xyz, q, k, v, idx, weights, packed=None):
+        return self.ptblock_attention(xyz, q, k, v, idx, tuple(weights))
+
     def ptblock_attention(self, xyz, q, k, v, idx, packed):
         """Unfused restatement of pointT_layer2.py:64-75 (after knn and the q/k/v projections)."""
         F = torch.nn.functional
         wd1, bd1, wd2, bd2, wg1, bg1, wg2, bg2 = packed
-        knn_xyz = orc.group_rows(xyz, idx.int())
-        kk, vv = orc.group_rows(k, idx.int()), orc.group_rows(v, idx.int())
+        knn_xyz = self.group_rows(xyz, idx)
+        kk, vv = self.group_rows(k, idx), self.group_rows(v, idx)
         pos = F.linear(torch.relu(F.linear(xyz.unsqueeze(2) - knn_xyz, wd1, bd1)), wd2, bd2)
         attn = F.linear(torch.relu(F.linear((q.unsqueeze(2) - kk) + pos, wg1, bg1)), wg2, bg2)
         attn = torch.softmax(attn / (kk.shape[-1] ** 0.5), dim=-2)
@@ -89,8 +107,8 @@ class OracleBackend:
         """Unfused restatement of mocopci.py:1218-1266 + :1289-1300 + :1330-1335."""
         F = torch.nn.functional
         B, S, _ = new_xyz.shape
-        g_xyz = orc.group_rows(s_xyz, idx.int()) - new_xyz.unsqueeze(2)
-        new_points = torch.cat([g_xyz, orc.group_rows(s_points, idx.int())], dim=-1)
+        g_xyz = self.group_rows(s_xyz, idx) - new_xyz.unsqueeze(2)
+        new_points = torch.cat([g_xyz, self.group_rows(s_points, idx)], dim=-1)
         w = g_xyz
         for ww, bb in ((w0, b0), (w1, b1), (w2, b2)):
             w = torch.relu(F.linear(w, ww, bb))
@@ -106,4 +124,7 @@ class OracleBackend:
         return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
 
     def chamfer(self, x, y):
-        return torch.tensor(orc.chamfer(x, y), dtype=torch.float32)
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):  # models/utils.py:36-45 with pytorch3d's defaults
+            d = ((x.unsqueeze(2) - y.unsqueeze(1)) ** 2).sum(-1)
+            return (d.min(2)[0].mean(1) + d.min(1)[0].mean(1)).mean()
+        return torch.tensor(orc.chamfer(x.detach(), y.detach()), dtype=torch.float32)

@@ -49,3 +49,28 @@ def test_hip_backend_refuses_cpu_tensors():
     be = ops.HipBackend()
     with pytest.raises(RuntimeError):
         be.fps(torch.zeros(1, 16, 3), 4)
+
+
+def test_training_forward_and_loss_on_the_oracle_backend(oracle_backend):
+    """MoCoPCI.forward(train=True) returns the reference's 4-tuple (mocopci.py:1076-1097) and train.py:135-160's objective
+    back-propagates to every parameter the reference's forward uses (CPU, N=1024; the -m gpu twin compares HIP against this)."""
+    from mocopci_amd import synth, training
+    x1, x2, gt = synth.make_batch(1, 1, 1024)
+    gtc = [g.transpose(1, 2).contiguous() for g in gt]
+    net = hc.build_model("cpu")
+    frames_f, frames_b, gt_frame, out = net(x1, x2, gtc, None, True)
+    assert len(frames_f) == len(frames_b) == len(gt_frame) == len(out) == 3
+    assert [tuple(t.shape) for t in frames_b[2]] == [(1, 1024, 3), (1, 1024, 3), (1, 2048, 3), (1, 512, 3), (1, 256, 3)]
+    assert [tuple(t.shape) for t in gt_frame[1]] == [(1, 3, 1024), (1, 3, 256), (1, 3, 64), (1, 3, 32)]
+    loss, parts = training.multiscale_loss(frames_f, frames_b, gt_frame, out, gtc)
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(v) for v in parts.values())
+    with_grad = {n for n, p in net.named_parameters() if p.grad is not None and torch.isfinite(p.grad).all()}
+    # modules the reference constructs but never calls (fusion_gru, recurrent0, rf_block0, deconv1_0, WeightNet's BatchNorms,
+    # the block outputs nobody reads) get none, exactly as in the reference
+    assert len(with_grad) >= 280 and "encoder.level0.linear.weight" in with_grad and "multi_frame_inference.cross3.pos1.weight" in with_grad
+    assert not any(n.startswith("multi_frame_inference.fusion_gru") for n in with_grad)
+    # the inference entry point is untouched by a training forward (no cached tensor holds a graph)
+    with torch.no_grad():
+        for a, b in zip(net(x1, x2), out):
+            assert a.shape == b.shape and not a.requires_grad
