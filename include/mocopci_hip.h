@@ -254,6 +254,7 @@ int mcp_emd(int b, int n, int m, const float *xyz1, const float *xyz2, float *ma
 #define MCP_KERNEL_CROSS 7
 #define MCP_KERNEL_POINTCONV 8
 #define MCP_KERNEL_ATTENTION 9
+#define MCP_KERNEL_PTBLOCK 10
 int mcp_prof_enable(int kernel_mask);
 int mcp_prof_collect(int kernel_id, int *launches, float *total_ms);
 

@@ -192,6 +192,8 @@ MCP_EXPORT int mcp_ptblock_attention(int b, int n, int c, int k, int qkv_stride,
     const long long want = ((total + 1) / 2 + WAVES * 4 - 1) / (WAVES * 4);  // >= 4 point pairs per wave: amortises the weight staging
     const unsigned grid = (unsigned)max(1LL, min(want, 768LL));
     const float scale_log2e = 1.44269504088896340736f / 8.0f;  // softmax(attn / sqrt(64)), pointT_layer2.py:73
+    mcp_prof_begin(MCP_KERNEL_PTBLOCK, s);
     hipLaunchKernelGGL(ptblock_kernel, dim3(grid), dim3(64 * WAVES), 0, s, total, n, qkv_stride, xyz, q, kf, vf, idx, packed, scale_log2e, out);
+    mcp_prof_end(MCP_KERNEL_PTBLOCK, s);
     return mcp_launch_status();
 }

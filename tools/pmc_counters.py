@@ -12,8 +12,9 @@ Units and corrections (same guide, HBM section and the SQ-units row of its const
     side is doubled; narrower gathers are uncalibrated, which makes hbm_bytes an upper estimate of the read side;
   * SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles
     summed over SIMDs; durations come from the dispatch timestamps of the same rows.
-Derived per family (formulas spelled out so nobody has to trust a name):
-  valu_issue_frac = 4 * SQ_ACTIVE_INST_VALU / (busy SIMD-cycles)   busy SIMD-cycles = 4 * SQ_BUSY_CYCLES_per_SE-summed ... see code
+Derived per family (formulas in the code below, spelled out so nobody has to trust a name): cycles = GRBM_GUI_ACTIVE / 8 (the
+counter sums the 8 XCDs); valu_busy_frac_of_chip = 4 * SQ_ACTIVE_INST_VALU / (cycles * 1024 SIMDs)  (VALUBusy, gfx94x formula);
+mfma_busy_frac_of_chip = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 1024)  (MfmaUtil); wave_time_* = share of resident-wave time.
 """
 import collections
 import csv
@@ -26,7 +27,7 @@ FAMILIES = {  # name -> kernel-name substrings
     "knn_pruned": ("knn_pruned_kernel",),
     "build_cloud": ("build_cloud_kernel",),
     "knn_cosine": ("knn_cosine_kernel",),
-    "fusion": ("fusion_kernel",),
+    "fusion": ("fusion_kernel", "fusion_split_kernel"),
     "cross": ("cross_kernel",),
     "pointconv": ("pointconv_agg_kernel",),
     "attention": ("attention_small_kernel", "attention_kernel"),
@@ -83,14 +84,16 @@ def main():
             for name, key in (("parked", "SQ_WAIT_ANY"), ("issue_stalled", "SQ_WAIT_INST_ANY")):
                 if key in c:
                     e[f"wave_time_{name}_frac"] = c[key] / wave
-            cycles = e["avg_dispatch_us_under_pmc"] * 1e3 * CLOCK_GHZ              # kernel duration in shader cycles (nominal clock)
+            # kernel duration in shader cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs, so /8 is the busy-cycle count at the
+            # clock the kernel actually ran at (MFMA-heavy kernels run near 2.0 GHz, not the nominal 2.4); nominal otherwise
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0 if "GRBM_GUI_ACTIVE" in c else e["avg_dispatch_us_under_pmc"] * 1e3 * CLOCK_GHZ
+            if "GRBM_GUI_ACTIVE" in c:
+                e["effective_clock_ghz"] = cycles / (e["avg_dispatch_us_under_pmc"] * 1e3)
             e["mean_resident_waves_per_simd"] = 4.0 * wave / (cycles * N_SIMD)
             if "SQ_ACTIVE_INST_VALU" in c:
                 e["valu_busy_frac_of_chip"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * N_SIMD)   # VALUBusy, gfx94x formula
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
                 e["mfma_busy_frac_of_chip"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * N_SIMD)   # MfmaUtil, gfx94x formula
-        if "GRBM_GUI_ACTIVE" in c:
-            e["grbm_gui_active_over_nominal_cycles"] = c["GRBM_GUI_ACTIVE"] / (e["avg_dispatch_us_under_pmc"] * 1e3 * CLOCK_GHZ)
         out[f] = e
     json.dump(out, open(out_path, "w"), indent=1)
     for f, e in out.items():

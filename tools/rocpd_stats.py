@@ -29,7 +29,7 @@ def main():
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
             for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
                 w.writerow([n, len(v), sum(v), round(sum(v) / len(v), 1), round(100 * sum(v) / tot, 3), min(v), max(v)])
-    fus = [i for i, r in enumerate(rows) if "fusion_kernel" in r[0]]
+    fus = [i for i, r in enumerate(rows) if "fusion_kernel" in r[0] or "fusion_split_kernel" in r[0]]
     a, b = fus[-3], fus[-2]
     step = rows[a + 1:b + 1]
     lines = []
