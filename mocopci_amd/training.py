@@ -34,4 +34,4 @@ def train_step(net, optimizer, xyz1, xyz2, gt, clip=2.0):
     loss.backward()
     torch.nn.utils.clip_grad_norm_(net.parameters(), clip)
     optimizer.step()
-    return float(loss), {k: float(v) for k, v in parts.items()}
+    return float(loss.detach()), {k: float(v.detach()) for k, v in parts.items()}
