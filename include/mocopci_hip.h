@@ -222,6 +222,20 @@ int mcp_attention_wide(int bf, int nq, int nk, int heads, int hd, const float *q
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
 
+/* Fused two-layer per-point MLP (Mlp_T of Multi_Frame_Att, mocopci.py:1558-1565 inside :551-575, and the flow heads
+ * trans_block / trans_block_2 -> mapping_xyz, :566-567 / :510-511):
+ *     out[r, 0:cout] = (res ? res[r] : 0) + b2 + W2 . act(W1 . x[r] + b1),   act(v) = v > 0 ? v : slope * v   (PReLU with one slope)
+ * x (rows, cin) with row stride x_stride floats (16-byte aligned rows), W1 (hidden, cin), W2 (cout, hidden); the (rows, hidden)
+ * activation is never written.  Supported (the shapes where it beats the BLAS chain): cin 64 (cout <= 64), cin 128 (cout <= 32);
+ * hidden a multiple of 32.  The weights are prepared once by mcp_mlp2_pack into mcp_mlp2_packed_floats(cin, hidden, cout) caller-owned
+ * floats (0 = unsupported shape).  Depthwise k=1 convolutions and eval-mode BatchNorms around the first layer are affine and are
+ * folded into (W1, b1) by the caller. */
+int mcp_mlp2_packed_floats(int cin, int hidden, int cout);
+int mcp_mlp2_pack(int cin, int hidden, int cout, const float *w1, const float *b1, const float *w2, const float *b2, float *packed,
+                  mcp_stream_t stream);
+int mcp_mlp2(long long rows, int cin, int hidden, int cout, float slope, const float *x, int x_stride, const float *res, int res_stride,
+             const float *packed, float *out, int out_stride, mcp_stream_t stream);
+
 /* Point-Transformer vector attention (TransformerBlock.forward, models/pointT_layer2.py:58-77; d_model 64, k 16) after the
  * neighbour search and the q/k/v projections: xyz (B,N,3), q/kf/vf (B,N,64) channel-last (16-byte aligned) with a common row
  * stride of qkv_stride floats (64 for separate tensors, 192 when they are slices of one packed projection), idx (B,N,16)
@@ -255,6 +269,7 @@ int mcp_emd(int b, int n, int m, const float *xyz1, const float *xyz2, float *ma
 #define MCP_KERNEL_POINTCONV 8
 #define MCP_KERNEL_ATTENTION 9
 #define MCP_KERNEL_PTBLOCK 10
+#define MCP_KERNEL_MLP 11
 int mcp_prof_enable(int kernel_mask);
 int mcp_prof_collect(int kernel_id, int *launches, float *total_ms);
 

@@ -114,6 +114,13 @@ def attention_twin(q, kv, heads, scale):
     return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
 
 
+def mlp2_twin(x, res, w1, b1, w2, b2, slope):
+    """Two-layer per-point MLP with a one-slope PReLU (Mlp_T, mocopci.py:1558-1565, with its affine neighbours folded in)."""
+    hid = F.linear(x, w1, b1)
+    out = F.linear(torch.where(hid > 0, hid, hid * slope), w2, b2)
+    return out if res is None else out + res
+
+
 def interp3_weights_twin(G, dense, sparse, idx3):
     """Inverse-distance weights of UpsampleFlow / PointWarping, mocopci.py:1475-1478, :1495-1498."""
     dist = torch.norm(G(sparse, idx3) - dense.unsqueeze(2), dim=3).clamp(min=1e-10)

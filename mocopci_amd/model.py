@@ -367,26 +367,41 @@ class MoCoPCI(nn.Module):
                                     scale=C ** -0.5)                              # (B*2,N,3C): 3 head slots, each C wide
         o = self.lin(o.reshape(B, Fr, N, 3, C).sum(dim=1).transpose(1, 2), a + ".proj")   # (B,3,N,C)
         t = prefix + ".trans_block_2"
-        hid = F.prelu(self.lin(o, t + ".fc1"), P[t + ".act.weight"])
         if not feats:  # only the flows are read (MultiFrameEstimatier.forward never uses cross_block3's features in inference)
-            return None, F.linear(hid, *self.folded_tail(t + ".fc2", prefix + ".mapping_xyz"))
-        xa = self.lin(hid, t + ".fc2")
+            return None, self.mlp_t(t, o, tail=prefix + ".mapping_xyz")
+        xa = self.mlp_t(t, o)
         frames = self.lin(xa, prefix + ".mapping_xyz")
         return xa, frames                                                         # (B,3,N,C), (B,3,N,3)
 
-    def mlp_t(self, prefix, x, tail=None):
-        """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2.  The depthwise k=1 conv is a
-        per-channel scale + bias, folded into fc1 once: (W x + b) * s + t = (s W) x + (s b + t)."""
+    def mlp_t(self, prefix, x, tail=None, res=None, bn=None):
+        """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2 -- as ONE fused kernel (ops.mlp2).  Everything
+        affine around the first layer is folded into it once: the depthwise k=1 conv is a per-channel scale + bias,
+        (W x + b) * s + t = (s W) x + (s b + t); bn = (name, eps) is an eval-mode BatchNorm applied to x first,
+        W (g x + h) + b = (W diag g) x + (W h + b).  tail: a Linear applied to the result (mapping_xyz), folded into fc2 where
+        only the 3-channel flow is read.  res: residual added to the result (inside the kernel)."""
         P = self._params()
+        be = ops.backend()
+
         def fold():
-            sc = P[prefix + ".dwconv.dwconv.weight"].reshape(-1)
-            return ((self.W(prefix + ".fc1") * sc[:, None]).contiguous(),
-                    (self.Bv(prefix + ".fc1") * sc + P[prefix + ".dwconv.dwconv.bias"]).contiguous())
-        w1, b1 = self.derived(("mlp_t_fc1", prefix), fold)
-        hid = F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"])
-        if tail is not None:
-            return F.linear(hid, *self.folded_tail(prefix + ".fc2", tail))
-        return self.lin(hid, prefix + ".fc2")
+            w1, b1 = self.W(prefix + ".fc1"), self.Bv(prefix + ".fc1")
+            if prefix + ".dwconv.dwconv.weight" in P:
+                sc = P[prefix + ".dwconv.dwconv.weight"].reshape(-1)
+                w1, b1 = w1 * sc[:, None], b1 * sc + P[prefix + ".dwconv.dwconv.bias"]
+            if bn is not None:
+                g = P[bn[0] + ".weight"] * torch.rsqrt(P[bn[0] + ".running_var"] + bn[1])
+                hsh = P[bn[0] + ".bias"] - P[bn[0] + ".running_mean"] * g
+                w1, b1 = w1 * g[None, :], b1 + w1 @ hsh
+            w2, b2 = self.folded_tail(prefix + ".fc2", tail) if tail is not None else (self.W(prefix + ".fc2"), self.Bv(prefix + ".fc2"))
+            return w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+        w1, b1, w2, b2 = self.derived(("mlp_t", prefix, tail, bn), fold)
+        live = self._live is not None
+        if not be.mlp2_supported(w1.shape[1], w1.shape[0], w2.shape[0]):  # widths the kernel is not built for (feature outputs)
+            out = F.linear(F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"]), w2, b2)
+            return out if res is None else out + res
+        # the PReLU slope: the live parameter in a training forward (it gets its gradient), a cached float otherwise
+        slope = P[prefix + ".act.weight"] if live else self.derived(("slope", prefix), lambda: float(P[prefix + ".act.weight"]))
+        packed = None if live else self.derived(("mlp_t_pack", be.name, prefix, tail, bn), lambda: be.mlp2_pack(w1, b1, w2, b2))
+        return be.mlp2(x, w1, b1, w2, b2, slope, res=res, packed=packed)
 
     def multi_frame_att(self, prefix, x, heads=8, rows=None, feats=True):
         """Multi_Frame_Att.forward (mocopci.py:551-575) batched, on the INNER frames only.  The reference runs 5 frames
@@ -405,8 +420,7 @@ class MoCoPCI(nn.Module):
                                     heads)                                         # (B*3,N,C)
         o = self.lin(o.reshape(B, Fr, N, C), a + ".proj")
         xn = xn + o
-        xb = self.mlp_t(prefix + ".mlp", self.bn_eval(xn, prefix + ".norm2", 1e-5))
-        x = x + xb
+        x = self.mlp_t(prefix + ".mlp", xn, res=x, bn=(prefix + ".norm2", 1e-5))   # x + mlp(norm2(xn)), mocopci.py:561-563
         if not feats:  # flows only: trans_block.fc2 and mapping_xyz collapse into one (4C -> 3) map
             return None, self.mlp_t(prefix + ".trans_block", x, tail=prefix + ".mapping_xyz")
         xf = self.mlp_t(prefix + ".trans_block", x)                               # (B,3,N,latent)

@@ -354,6 +354,42 @@ class HipBackend:
               float(scale), out.data_ptr(), C)
         return out
 
+    def mlp2_pack(self, w1, b1, w2, b2):
+        """Operand image of one two-layer MLP for mlp2 (split once; do this once per block)."""
+        hidden, cin = w1.shape
+        cout = w2.shape[0]
+        n = _lib.load().mcp_mlp2_packed_floats(cin, hidden, cout)
+        if n == 0:
+            raise RuntimeError(f"mlp2 does not support cin={cin}, hidden={hidden}, cout={cout}")
+        packed = torch.empty((n,), dtype=torch.float32, device=w1.device)
+        _call("mcp_mlp2_pack", w1, cin, hidden, cout, _lib.fptr(w1.contiguous()), _lib.fptr(b1.contiguous()), _lib.fptr(w2.contiguous()),
+              _lib.fptr(b2.contiguous()), _lib.fptr(packed))
+        return packed
+
+    def mlp2(self, x, w1, b1, w2, b2, slope, res=None, packed=None):
+        """out = [res +] W2 act(W1 x + b1) + b2 over the last axis, act = PReLU with one slope: Mlp_T and the flow heads of the
+        frame-attention blocks (mocopci.py:1558-1565, :566-567, :510-511) as ONE kernel; the hidden activation is never written.
+        x (..., cin) -> (..., cout); slope: a float, or the 1-element PReLU parameter (then it receives a gradient too).
+        Differentiable w.r.t. x, res and the weights.  packed: mlp2_pack(w1, b1, w2, b2) when the caller keeps one."""
+        def fused(x_, res_, w1_, b1_, w2_, b2_, slope_):
+            pk = packed if packed is not None else self.mlp2_pack(w1_, b1_, w2_, b2_)
+            cin, hidden, cout = w1_.shape[1], w1_.shape[0], w2_.shape[0]
+            x2 = x_.reshape(-1, cin)
+            if not (x2.stride(1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0):
+                x2 = x2.contiguous()
+            r2 = None if res_ is None else res_.reshape(-1, cout).contiguous()
+            out = torch.empty((x2.shape[0], cout), dtype=torch.float32, device=x_.device)
+            _call("mcp_mlp2", x_, x2.shape[0], cin, hidden, cout, float(slope_), x2.data_ptr(), x2.stride(0), None if r2 is None else _lib.fptr(r2), cout,
+                  _lib.fptr(pk), _lib.fptr(out), cout)
+            return out.reshape(*x_.shape[:-1], cout)
+        return grad.run(fused, grad.mlp2_twin, x, res, w1, b1, w2, b2, slope)
+
+    def mlp2_supported(self, cin, hidden, cout):
+        """Shapes the fused kernel is built for (the ones where it beats the BLAS chain); MCP_NO_MLP2=1 turns it off for A/B runs."""
+        return not self._NO_MLP2 and _lib.load().mcp_mlp2_packed_floats(cin, hidden, cout) != 0
+
+    _NO_MLP2 = os.environ.get("MCP_NO_MLP2", "0") == "1"
+
     def chamfer(self, x, y):
         """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor.  As a training loss
         (train.py:135-160) it is differentiable w.r.t. both clouds: the nearest neighbours come from the search kernel and the
@@ -386,7 +422,7 @@ def set_backend(b):
 
 
 # ---- instrumentation passthrough (bench.py) ----
-KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7, "pointconv": 8, "attention": 9, "ptblock": 10}
+KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7, "pointconv": 8, "attention": 9, "ptblock": 10, "mlp": 11}
 
 
 def prof_enable(kernel_names):

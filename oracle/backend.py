@@ -123,6 +123,18 @@ class OracleBackend:
         o = torch.nn.functional.scaled_dot_product_attention(qh, kvh[0], kvh[1], scale=scale)
         return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
 
+    def mlp2_pack(self, w1, b1, w2, b2):
+        return None
+
+    def mlp2(self, x, w1, b1, w2, b2, slope, res=None, packed=None):
+        """Linear, one-slope PReLU, Linear (+ residual): Mlp_T with its affine neighbours folded in, mocopci.py:1558-1565."""
+        hid = torch.nn.functional.linear(x, w1, b1)
+        out = torch.nn.functional.linear(torch.where(hid > 0, hid, hid * slope), w2, b2)
+        return out if res is None else out + res
+
+    def mlp2_supported(self, cin, hidden, cout):
+        return True
+
     def chamfer(self, x, y):
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):  # models/utils.py:36-45 with pytorch3d's defaults
             d = ((x.unsqueeze(2) - y.unsqueeze(1)) ** 2).sum(-1)

@@ -61,3 +61,12 @@ def test_ptblock_and_wide_attention_are_deterministic():
     assert repeatable(lambda: be.attention(q, kv, 8))
     q, kv = rnd(48, 2048, 64), rnd(48, 2048, 128)
     assert repeatable(lambda: be.attention(q, kv, 8))
+
+
+def test_mlp2_is_deterministic():
+    torch.manual_seed(2)
+    be = ops.backend()
+    x, res = rnd(49152, 64), rnd(49152, 64)
+    pk = be.mlp2_pack(rnd(256, 64, scale=0.125), rnd(256, scale=0.1), rnd(64, 256, scale=0.06), rnd(64, scale=0.1))
+    w = (rnd(256, 64), rnd(256), rnd(64, 256), rnd(64))  # shapes only: the packed image carries the values
+    assert repeatable(lambda: be.mlp2(x, *w, 0.25, res=res, packed=pk))

@@ -122,6 +122,16 @@ def test_interp3_gradients_reach_features_and_coordinates(n, s, c):
     compare_grads(lambda a, b, f: be.interp3(a, b, f), lambda a, b, f: ob.interp3(a, b, f), [dense, sparse, feat], names=["dense", "sparse", "feat"])
 
 
+@pytest.mark.parametrize("cin,hidden,cout", [(64, 256, 64), (128, 512, 3)])  # both heads of the two levels
+def test_mlp2_gradients(cin, hidden, cout):
+    x, res = rnd(90, 2, 300, cin), rnd(91, 2, 300, cout)
+    w = [rnd(92, hidden, cin, scale=cin ** -0.5), rnd(93, hidden, scale=0.1), rnd(94, cout, hidden, scale=hidden ** -0.5), rnd(95, cout, scale=0.1)]
+    slope = torch.tensor([0.25])
+    ob, be = OracleBackend(), ops.backend()
+    compare_grads(lambda a, r, w1, b1, w2, b2, sl: be.mlp2(a, w1, b1, w2, b2, sl, res=r), lambda a, r, w1, b1, w2, b2, sl: ob.mlp2(a, w1, b1, w2, b2, sl, res=r),
+                  [x, res, *w, slope], names=["x", "res", "w1", "b1", "w2", "b2", "slope"])
+
+
 def test_chamfer_gradients():
     x, y = cloud(80, 2, 500), cloud(81, 2, 700)
     ob, be = OracleBackend(), ops.backend()

@@ -542,3 +542,25 @@ def test_search_on_a_reused_buffer_sees_the_new_contents():
     ops._call("mcp_group_rows", src, 1, 4096, 3, 4096, src.data_ptr(), ar.data_ptr(), buf.data_ptr())  # raw write, no version bump
     assert torch.equal(buf.cpu(), b)
     assert torch.equal(be.knn(buf, buf, 16).cpu(), orc.knn(b, b, 16))
+
+
+@pytest.mark.parametrize("cin,hidden,cout,rows,with_res", [(64, 256, 64, 5000, True), (64, 256, 3, 4096, False), (128, 512, 3, 1000, False),
+                                                           (128, 512, 32, 3000, True), (64, 256, 64, 31, True)])
+def test_mlp2_matches_unfused_oracle(cin, hidden, cout, rows, with_res):
+    """Fused two-layer MLP (Mlp_T / flow heads, mocopci.py:1558-1565, :566-567, :510-511) against the oracle backend's unfused
+    Linear - PReLU - Linear (+ residual); x read through a row stride (a column slice of a wider tensor) as the model does."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(cin + hidden + cout)
+    wide = torch.randn(2, rows, cin + 8, generator=g)
+    x = wide[..., :cin]
+    res = torch.randn(2, rows, cout, generator=g) if with_res else None
+    w1, b1 = torch.randn(hidden, cin, generator=g) / cin ** 0.5, torch.randn(hidden, generator=g) * 0.1
+    w2, b2 = torch.randn(cout, hidden, generator=g) / hidden ** 0.5, torch.randn(cout, generator=g) * 0.1
+    want = OracleBackend().mlp2(x, w1, b1, w2, b2, 0.25, res=res)
+    be = ops.backend()
+    dw = [t.to(DEV) for t in (w1, b1, w2, b2)]
+    got = be.mlp2(wide.to(DEV)[..., :cin], *dw, 0.25, res=None if res is None else res.to(DEV))
+    assert got.shape == want.shape
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
+    got2 = be.mlp2(x.contiguous().to(DEV), *dw, 0.25, res=None if res is None else res.to(DEV), packed=be.mlp2_pack(*dw))
+    assert torch.equal(got, got2)

@@ -47,6 +47,15 @@ def main():
             per[short(n)][1] += 1
         for k, (t, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:40]:
             lines.append(f"    {t / 1e6:7.3f} ms  {c:4d}x  {k}")
+    # where the main queue (the busiest one) sits idle inside the step: gaps above 15 us with the kernels on both sides
+    main_q = max(queues, key=lambda q: sum(e - s for _, s, e, _ in queues[q]))
+    rs = sorted(queues[main_q], key=lambda r: r[1])
+    gaps = [(rs[i + 1][1] - rs[i][2], short(rs[i][0]), short(rs[i + 1][0]), (rs[i][2] - step[0][1]) / 1e6) for i in range(len(rs) - 1)]
+    small = sum(g for g, *_ in gaps if 0 < g <= 15000) / 1e6
+    lines.append(f"main queue {main_q}: idle {sum(max(g, 0) for g, *_ in gaps) / 1e6:.3f} ms; {small:.3f} ms of it in gaps <= 15 us ({sum(1 for g, *_ in gaps if 0 < g <= 15000)} boundaries)")
+    for g, a, b, at in sorted(gaps, key=lambda t: -t[0])[:14]:
+        if g > 15000:
+            lines.append(f"    gap {g / 1e3:7.1f} us at +{at:6.3f} ms  after {a}  before {b}")
     text = "\n".join(lines)
     print(text)
     if len(sys.argv) > 3:
