@@ -178,8 +178,9 @@ int mcp_interp3_apply_grad(int b, int n, int s, int c, const float *grad_out, co
  * followed by 32 neighbours of p1 in p2); per neighbour [d, |d|] -> 4->64->64->128 (1x1 conv + eval
  * BatchNorm folded into w,b by the caller + ReLU) -> channel max -> softmax over the 64 neighbours ->
  * weighted sum of neighbour coordinates -> out (B,N,3).  w1 (64,4), w2 (64,64), w3 (128,64) row-major.
- * nb must be 64 (the reference's fixed k = 32 + 32). */
-int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const float *w1, const float *b1,
+ * nb must be 64 (the reference's fixed k = 32 + 32).  idx2 == NULL: idx is the (B,N,64) list; otherwise idx and idx2 are its
+ * two halves as separate (B,N,32) lists, exactly as the two searches produce them (no concatenation pass). */
+int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1,
                const float *w2, const float *b2, const float *w3, const float *b3, float *out, mcp_stream_t stream);
 
 /* Cost-volume cross() after its neighbour searches (pointconv_util.py:750-781, :894-922, :1126-1161):
@@ -188,12 +189,13 @@ int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int
  * neighbours of LeakyReLU(wmlp . LeakyReLU(points2[idx] + points1 + wpos.(xyz2[idx]-xyz1) + bpos) + bmlp).
  * The layer's weights -- wpos (D,3), bpos (D) = the Conv2d 3->D; wmlp (D,D), bmlp (D) = the single Conv2d D->D of
  * the mlp list (every layer MoCoPCI builds has exactly one) -- are packed ONCE per layer by mcp_cross_pack into
- * the MFMA-operand image (mcp_cross_packed_floats(D) floats, 16-byte aligned, caller-owned).  D in {64,128}, k = 32. */
+ * the MFMA-operand image (mcp_cross_packed_floats(D) floats, 16-byte aligned, caller-owned).  D in {64,128}, k = 32.  Neighbour lists: idx (B,N1,32), or with idx2 != NULL
+ * the 16 + 16 halves as two (B,N1,16) lists (feature-space neighbours, then coordinate-space neighbours). */
 int mcp_cross_packed_floats(int d);
 int mcp_cross_pack(int d, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, float *packed,
                    mcp_stream_t stream);
 int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
-                     const float *points2, const int *idx, const float *packed, float *out, mcp_stream_t stream);
+                     const float *points2, const int *idx, const int *idx2, const float *packed, float *out, mcp_stream_t stream);
 
 /* PointConv / PointConvD up to the final Linear (mocopci.py:1218-1266, :1289-1300, :1330-1335):
  * s_xyz (B,N,3), new_xyz (B,S,3) centres, s_points (B,N,D) channel-last, idx (B,S,32) int32 into the

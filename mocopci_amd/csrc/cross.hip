@@ -139,7 +139,8 @@ template <int D, int SPLIT>
 __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
                                                            const float *__restrict__ xyz2, const float *__restrict__ points1,
                                                            const float *__restrict__ points2, const int *__restrict__ idx,
-                                                           const float *__restrict__ packed, float *__restrict__ out) {
+                                                           const int *__restrict__ idx2, const float *__restrict__ packed,
+                                                           float *__restrict__ out) {
     using L = CrossLds<D>;
     constexpr int T = L::T, KQ = T * 4;  // k-quads per output tile (f32 image)
     constexpr int WAVES = CrossShape<D>::NW;
@@ -183,11 +184,13 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
                 rg[t][g] = row2[(32 * t + 8 * g + 4 * h) >> 2];
             }
     };
+    // idx2 != NULL: the 16 feature-space and the 16 coordinate-space neighbours come as two (B,N1,16) lists
+    auto nbr = [&](long long pp) { return idx2 ? (col < 16 ? idx[pp * 16 + col] : idx2[pp * 16 + col - 16]) : idx[pp * KNB + col]; };
     long long pn = p + stride;
     int idn = 0;
     if (p < total) {
-        fetch(p, idx[p * KNB + col]);
-        if (pn < total) idn = idx[pn * KNB + col];
+        fetch(p, nbr(p));
+        if (pn < total) idn = nbr(pn);
     }
     for (; p < total; p = pn, pn += stride) {
         f32x16 x0[L::BF ? 1 : T];
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
         }
         if (pn < total) {
             fetch(pn, idn);
-            if (pn + stride < total) idn = idx[(pn + stride) * KNB + col];
+            if (pn + stride < total) idn = nbr(pn + stride);
         }
 #pragma unroll 1
         for (int tl = 0; tl < TO; ++tl) {
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
 
 template <int D, int SPLIT>
 int launch_cross(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
-                 const int *idx, const float *packed, float *out, hipStream_t s) {
+                 const int *idx, const int *idx2, const float *packed, float *out, hipStream_t s) {
     using L = CrossLds<D>;
     const size_t lds = (L::W_FLOATS / SPLIT + L::POS_FLOATS + L::B_FLOATS) * sizeof(float);
     auto kern = cross_kernel<D, SPLIT>;
@@ -263,7 +266,7 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
     // persistent-style grid = exactly the resident slots (256 CUs x 3 or 2 workgroups, see __launch_bounds__): a larger
     // grid leaves a partly filled second round of workgroups
     const unsigned grid = (unsigned)max(1LL, min(want, (long long)(CrossShape<D>::GRID / SPLIT)));
-    hipLaunchKernelGGL(kern, dim3(grid, SPLIT), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out);
+    hipLaunchKernelGGL(kern, dim3(grid, SPLIT), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, packed, out);
     return mcp_launch_status();
 }
 
@@ -286,16 +289,16 @@ MCP_EXPORT int mcp_cross_pack(int d, const float *wpos, const float *bpos, const
 }
 
 MCP_EXPORT int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
-                                const float *points2, const int *idx, const float *packed, float *out, mcp_stream_t stream) {
+                                const float *points2, const int *idx, const int *idx2, const float *packed, float *out, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && packed && out);
     if (k != KNB || (d != 64 && d != 128 && d != 256)) return MCP_ERR_UNSUPPORTED;
     if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)out) | ((uintptr_t)packed)) & 15) return MCP_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)b * n1;
     mcp_prof_begin(MCP_KERNEL_CROSS, s);
-    const int rc = d == 64    ? launch_cross<64, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s)
-                   : d == 128 ? launch_cross<128, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s)
-                              : launch_cross<256, 2>(total, n1, n2, xyz1, xyz2, points1, points2, idx, packed, out, s);
+    const int rc = d == 64    ? launch_cross<64, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, packed, out, s)
+                   : d == 128 ? launch_cross<128, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, packed, out, s)
+                              : launch_cross<256, 2>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, packed, out, s);
     mcp_prof_end(MCP_KERNEL_CROSS, s);
     return rc;
 }

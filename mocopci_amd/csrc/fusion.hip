@@ -55,7 +55,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __global__ __launch_bounds__(64 * WAVES, 2) void fusion_kernel(long long total, int n, const float *__restrict__ p1,
-                                                            const float *__restrict__ p2, const int *__restrict__ idx,
+                                                            const float *__restrict__ p2, const int *__restrict__ idx, const int *__restrict__ idx2,
                                                             const float *__restrict__ w1, const float *__restrict__ b1,
                                                             const float *__restrict__ w2, const float *__restrict__ b2,
                                                             const float *__restrict__ w3, const float *__restrict__ b3,
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_kernel(long long total, 
         float score[2], nbx[2], nby[2], nbz[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const int id = idx[p * NB + 32 * ct + col];
+            // idx2 != NULL: the two 32-neighbour halves come as separate (B,N,32) lists (no concatenation pass by the caller)
+            const int id = idx2 ? (ct ? idx2 : idx)[p * 32 + col] : idx[p * NB + 32 * ct + col];
             const float *q = p2 + ((long long)bb * n + id) * 3;
             const float x = q[0], y = q[1], z = q[2];
             nbx[ct] = x; nby[ct] = y; nbz[ct] = z;
@@ -182,7 +183,7 @@ constexpr int SP_W2_U4 = 2 * 4 * 3 * 64, SP_W3_U4 = 4 * 4 * 3 * 64;             
 constexpr size_t SP_LDS_BYTES = SP_F32_FLOATS * 4 + (size_t)(SP_W2_U4 + SP_W3_U4) * 16;
 
 __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long total, int n, const float *__restrict__ p1,
-                                                                  const float *__restrict__ p2, const int *__restrict__ idx,
+                                                                  const float *__restrict__ p2, const int *__restrict__ idx, const int *__restrict__ idx2,
                                                                   const float *__restrict__ w1, const float *__restrict__ b1,
                                                                   const float *__restrict__ w2, const float *__restrict__ b2,
                                                                   const float *__restrict__ w3, const float *__restrict__ b3,
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
         float score[2], nbx[2], nby[2], nbz[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const int id = idx[p * NB + 32 * ct + col];
+            // idx2 != NULL: the two 32-neighbour halves come as separate (B,N,32) lists (no concatenation pass by the caller)
+            const int id = idx2 ? (ct ? idx2 : idx)[p * 32 + col] : idx[p * NB + 32 * ct + col];
             const float *q = p2 + ((long long)bb * n + id) * 3;
             const float x = q[0], y = q[1], z = q[2];
             nbx[ct] = x; nby[ct] = y; nbz[ct] = z;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
 
 }  // namespace
 
-MCP_EXPORT int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const float *w1,
+MCP_EXPORT int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1,
                           const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *out,
                           mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && p1 && p2 && idx && w1 && b1 && w2 && b2 && w3 && b3 && out);
@@ -289,13 +291,13 @@ MCP_EXPORT int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2
     static const bool f32_mfma = [] { const char *v = getenv("MCP_FUSION_F32_MFMA"); return v && *v == '1'; }();
     mcp_prof_begin(MCP_KERNEL_FUSION, s);
     if (f32_mfma) {
-        hipLaunchKernelGGL(fusion_kernel, dim3(grid), dim3(64 * WAVES), 0, s, total, n, p1, p2, idx, w1, b1, w2, b2, w3, b3, out);
+        hipLaunchKernelGGL(fusion_kernel, dim3(grid), dim3(64 * WAVES), 0, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, out);
     } else {
         static McpPerDeviceOnce attr_once;
         if (attr_once.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fusion_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
-        hipLaunchKernelGGL(fusion_split_kernel, dim3(grid), dim3(64 * WAVES), SP_LDS_BYTES, s, total, n, p1, p2, idx, w1, b1, w2, b2, w3, b3,
+        hipLaunchKernelGGL(fusion_split_kernel, dim3(grid), dim3(64 * WAVES), SP_LDS_BYTES, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3,
                            out);
     }
     mcp_prof_end(MCP_KERNEL_FUSION, s);

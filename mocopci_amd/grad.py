@@ -65,6 +65,11 @@ def run(fused, twin, *args):
     return fused(*args)
 
 
+def whole(idx):
+    """A neighbour list given as its two halves (the two searches' outputs) or as one tensor -> one tensor."""
+    return torch.cat(list(idx), dim=-1) if isinstance(idx, (tuple, list)) else idx
+
+
 # ---- twins: the layers in unfused, differentiable form.  G = the differentiable row gather (ops.HipBackend.group_rows) ----
 def pointconv_agg_twin(G, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
     """group / group_query + WeightNet + aggregation, mocopci.py:1218-1266, :1289-1300, :1330-1335."""
@@ -78,14 +83,16 @@ def pointconv_agg_twin(G, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2)
 
 
 def cross_twin(G, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp):
-    """cross() after its neighbour searches, pointconv_util.py:765-781 (one mlp layer)."""
+    """cross() after its neighbour searches, pointconv_util.py:765-781 (one mlp layer).  idx: (B,N1,32) or its two halves."""
+    idx = whole(idx)
     direction = G(xyz2, idx) - xyz1.unsqueeze(2)
     x = F.leaky_relu((G(points2, idx) + points1.unsqueeze(2)) + F.linear(direction, wpos, bpos), 0.1)
     return F.leaky_relu(F.linear(x, wmlp, bmlp), 0.1).max(dim=2)[0]
 
 
 def fusion_twin(G, p1, p2, idx, w1, b1, w2, b2, w3, b3):
-    """knn_group + fusion after the searches, mocopci.py:803-819 (BatchNorm already folded into (w, b))."""
+    """knn_group + fusion after the searches, mocopci.py:803-819 (BatchNorm already folded into (w, b)).  idx: (B,N,64) or halves."""
+    idx = whole(idx)
     nb = G(p2, idx)
     resi = nb - p1.unsqueeze(2)
     x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)

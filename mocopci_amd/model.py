@@ -289,7 +289,7 @@ class MoCoPCI(nn.Module):
             idx_p = be.knn(xyz2, xyz1, 16, mode=ops.MCP_DIST_DIRECT)
         else:
             idx_p = be.knn(xyz1, xyz2, 16)
-        idx = torch.cat([idx_c, idx_p], dim=-1)                           # (B,N1,32)
+        idx = (idx_c.contiguous(), idx_p)                                 # the two 16-neighbour lists, read in place by the kernel
         # every cross() MoCoPCI builds has one D -> D mlp layer with D in {64, 128, 256} (pointconv_util.py:735-748)
         assert len(mlp) == 1 and points2.shape[-1] == points1.shape[-1]
         conv = mlp[0] + ".composed_module.0"
@@ -463,6 +463,15 @@ class MoCoPCI(nn.Module):
             self._time_cache[key] = enc.to(device)
         return self._time_cache[key]
 
+    def time_pair(self, B, dim, device):
+        """Time codes of the forward (rows [:B]) and backward (rows [B:]) decoder directions, (2B,5,1,dim); built once per shape."""
+        key = ("time_pair", B, dim, str(device))
+        self.__dict__.setdefault("_time_cache", {})
+        if key not in self._time_cache:
+            self._time_cache[key] = torch.cat([self.time_code(self.T_F, dim, device).expand(B, -1, -1),
+                                               self.time_code(self.T_B, dim, device).expand(B, -1, -1)], dim=0).unsqueeze(2).contiguous()
+        return self._time_cache[key]
+
     def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None, idx_c12=None):
         """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C)."""
         c1 = torch.cat([f1_0, f1_1, f1_new], dim=-1)
@@ -558,7 +567,7 @@ class MoCoPCI(nn.Module):
         m = "multi_frame_inference.conv."
         if idx_self is None:
             idx_self = be.knn(p1, p1, k)
-        idx = torch.cat([idx_self, be.knn(p1, p2, k)], dim=-1)                     # (B,N,2k) both index p2
+        idx = (idx_self, be.knn(p1, p2, k))                                        # 2 x (B,N,k), both index p2
         wb = [t for ci, bi in ((0, 1), (3, 4), (6, 7)) for t in self.folded_conv_bn(m + str(ci), m + str(bi), 1e-3)]
         return be.fusion_mlp(p1, p2.contiguous(), idx, *wb)
 
@@ -606,8 +615,7 @@ class MoCoPCI(nn.Module):
         # l2 (mocopci.py:870-911): rows [:B] = forward direction, rows [B:] = backward direction
         ups = self.interp_flows(pcs[2], pcs[3], frame3s, cache, "32")
         C = feats[2].shape[-1]
-        te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
-                       dim=0).unsqueeze(2)                                          # (2B,5,1,C)
+        te = self.time_pair(B, C, dev)                                              # (2B,5,1,C)
         fus[2] = early.get(("fus", 2))
         frame2s, n1_2, n2_2 = self.multiframe_attention(m + "multi_frame_up_2", pcs[2], pcs_o[2], f_l3_2, sw(f_l3_2), feats[2], fus[2],
                                                         feats_o[2], fus[2], ups, te, idx_c12=early.get(("cos", 2)))  # (2B,3,N2,3)
@@ -620,8 +628,7 @@ class MoCoPCI(nn.Module):
         f_up_1_o = torch.cat([f1_up[B:], f2_up[:B]], dim=0)
         ups = self.interp_flows(pcs[1], pcs[2], frame2s, cache, "21")
         C = feats[1].shape[-1]
-        te = torch.cat([self.time_code(self.T_F, C, dev).expand(B, -1, -1), self.time_code(self.T_B, C, dev).expand(B, -1, -1)],
-                       dim=0).unsqueeze(2)
+        te = self.time_pair(B, C, dev)
         # l0 (mocopci.py:997-1053).  Output frames 0,1 use the forward branch (flow index i on frame 1);
         # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).  Of the level-1 flows
         # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.

@@ -258,7 +258,9 @@ class HipBackend:
         p1, p2, w1, b1, w2, b2, w3, b3 = (t.contiguous() for t in (p1, p2, w1, b1, w2, b2, w3, b3))
         B, N, _ = p1.shape
         out = torch.empty((B, N, 3), dtype=torch.float32, device=p1.device)
-        _call("mcp_fusion", p1, B, N, idx.shape[-1], _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(idx), _lib.fptr(w1), _lib.fptr(b1),
+        ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)   # the two searches' lists as they are, or one (B,N,64) list
+        nb = ia.shape[-1] if ib is None else ia.shape[-1] + ib.shape[-1]
+        _call("mcp_fusion", p1, B, N, nb, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib), _lib.fptr(w1), _lib.fptr(b1),
               _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(w3), _lib.fptr(b3), _lib.fptr(out))
         return out
 
@@ -280,8 +282,10 @@ class HipBackend:
         B, N1, D = points1.shape
         N2 = points2.shape[1]
         out = torch.empty((B, N1, D), dtype=torch.float32, device=points1.device)
-        _call("mcp_cross_volume", points1, B, N1, N2, D, idx.shape[-1], _lib.fptr(xyz1), _lib.fptr(xyz2), _lib.fptr(points1),
-              _lib.fptr(points2), _lib.iptr(idx), _lib.fptr(packed), _lib.fptr(out))
+        ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)   # the 16 + 16 halves as the searches produce them, or one list
+        k = ia.shape[-1] if ib is None else ia.shape[-1] + ib.shape[-1]
+        _call("mcp_cross_volume", points1, B, N1, N2, D, k, _lib.fptr(xyz1), _lib.fptr(xyz2), _lib.fptr(points1),
+              _lib.fptr(points2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib), _lib.fptr(packed), _lib.fptr(out))
         return out
 
     def cross_layer(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, packed=None):

@@ -62,6 +62,7 @@ class OracleBackend:
 
     def fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
         """Unfused restatement of mocopci.py:803-819 with BN already folded into (w,b)."""
+        idx = torch.cat(list(idx), dim=-1) if isinstance(idx, (tuple, list)) else idx
         nb = self.group_rows(p2, idx)
         resi = nb - p1.unsqueeze(2)
         x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)
@@ -75,6 +76,7 @@ class OracleBackend:
 
     def cross_volume(self, xyz1, xyz2, points1, points2, idx, packed):
         """Unfused restatement of pointconv_util.py:765-781 (one mlp layer)."""
+        idx = torch.cat(list(idx), dim=-1) if isinstance(idx, (tuple, list)) else idx
         wpos, bpos, wmlp, bmlp = packed
         F = torch.nn.functional
         direction = self.group_rows(xyz2, idx) - xyz1.unsqueeze(2)
