@@ -37,7 +37,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 SPLIT_PRODUCTS = 6              # bf16 partial products per fp32 product on the split path (mocopci_amd/csrc/mfma_split.h)
 NPOINTS = 8192
 B_PER_GPU = 8
-FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock")
+FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock", "mlp")
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
 
 NAMES = {
@@ -49,6 +49,7 @@ NAMES = {
     "pointconv": "pointconv_agg_kernel (mcp_pointconv_agg)",
     "attention": "attention_small_kernel<8|16> / attention_wide_kernel<32|256> (mcp_attention_small, mcp_attention_wide)",
     "ptblock": "ptblock_kernel (mcp_ptblock_attention)",
+    "mlp": "mlp2_kernel (mcp_mlp2)",
 }
 NOTES = {
     "fps": "achieved/frac = SURVEY 8(d)'s figure: bytes of the REFERENCE'S streaming formulation B*(M-1)*20*N over kernel time -- NOT a "
@@ -65,6 +66,7 @@ NOTES = {
                  "(the gathers hit L2 / Infinity Cache)",
     "attention": "4*BF*H*Nq*Nk*hd flop; S = QK^T on the f32-input MFMA, softmax and (head dims 8/16) P.V on the VALU",
     "ptblock": "B*N*16*2*(3*64 + 3*64^2) flop; the three 64x64 layers on the split-bf16 path",
+    "mlp": "2*rows*(C*H + H*C_out) flop of the fused Mlp_T / flow-head blocks on the split-bf16 path, weights streamed through LDS",
 }
 
 
@@ -86,6 +88,8 @@ def algorithmic_work(kernel, calls):
         return sum(4 * bf * h * nq * nk * hd for (bf, h, nq, nk, hd) in calls), "flops"
     if kernel == "ptblock":
         return sum(b * n * 16 * 2 * (3 * 64 + 3 * 64 * 64) for (b, n) in calls), "flops"
+    if kernel == "mlp":
+        return sum(2 * rows * (c * h + h * co) for (rows, c, h, co) in calls), "flops"
     raise KeyError(kernel)
 
 
@@ -94,7 +98,7 @@ def log_call_shapes(be, step):
     3-NN searches inside interp3 / interp3_search reach the timer through be.knn, so only be.knn records them; the fused
     small-level mcp_interp3 call (its own KNN launch inside the library) records here."""
     calls = {k: [] for k in FAMILIES}
-    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "ptblock_attention")
+    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "ptblock_attention", "mlp2")
     orig = {n: getattr(be, n) for n in names}
 
     def wrap(name, rec):
@@ -116,6 +120,7 @@ def log_call_shapes(be, step):
     be.pointconv_agg = wrap("pointconv_agg", lambda sx, nx, sp, *a: calls["pointconv"].append((nx.shape[0], nx.shape[1], sp.shape[2])))
     be.attention = wrap("attention", lambda q, kv, h, **kw: calls["attention"].append((q.shape[0], h, q.shape[1], kv.shape[1], q.shape[2] // h)))
     be.ptblock_attention = wrap("ptblock_attention", lambda xyz, q, *a: calls["ptblock"].append((q.shape[0], q.shape[1])))
+    be.mlp2 = wrap("mlp2", lambda x, w1, b1, w2, *a, **k: calls["mlp"].append((x.numel() // x.shape[-1], w1.shape[1], w1.shape[0], w2.shape[0])))
     try:
         step()
     finally:
@@ -138,7 +143,7 @@ def roofline_entries(timed, calls, steps, pmc):
         if unit == "bytes":
             ach, peak, u, bound = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
         else:
-            peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_PRODUCTS if kname in ("fusion", "cross", "ptblock") else MFMA_F32_PEAK_TFLOPS
+            peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_PRODUCTS if kname in ("fusion", "cross", "ptblock", "mlp") else MFMA_F32_PEAK_TFLOPS
             ach, u, bound = per_launch / avg_s / 1e12, "TFLOP/s", "mfma"
         e = {"kernel": NAMES[kname], "bound": bound, "achieved": ach, "peak": peak, "unit": u, "frac": ach / peak,
              "traffic": None, "launches": launches, "launches_per_step": launches // steps, "avg_launch_us": 1e6 * avg_s,
