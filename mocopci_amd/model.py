@@ -201,27 +201,39 @@ class MoCoPCI(nn.Module):
             sides[key] = torch.cuda.Stream(device=device)
         return sides[key]
 
-    def run_encoder(self, xyz, early=None):
+    def sample_pyramid(self, xyz, side):
+        """The four FPS levels (mocopci.py:445-463) issued on the side stream: they depend only on the coordinates.  Returns
+        ([xyz, pc1..pc4], sel1, {level: ready event}); the caller's stream waits for a level only where it first reads it."""
+        main = torch.cuda.current_stream(xyz.device)
+        ready = {}
+        with torch.cuda.stream(side):
+            pcs = [xyz]
+            sel1 = None
+            for lvl, npoint in enumerate((2048, 512, 256, 64), start=1):
+                pts, sel = self.fps_gather(pcs[-1], npoint, return_idx=True)
+                pcs.append(pts)
+                sel1 = sel if lvl == 1 else sel1
+                ready[lvl] = torch.cuda.Event()
+                ready[lvl].record(side)
+        for t in (*pcs[1:], sel1):  # allocated on the side stream, consumed on the main stream
+            t.record_stream(main)
+        return pcs, sel1, ready
+
+    def run_encoder(self, xyz, early=None, pyramid=None):
         """PointConvEncoder.forward (mocopci.py:438-468), color == xyz.  The four FPS levels depend only on the
-        coordinates, so the whole sampling pyramid is issued up front on the side stream."""
+        coordinates, so the whole sampling pyramid is issued up front on the side stream.  pyramid: the result of
+        sample_pyramid when the caller already issued it (forward(inputs_ready=...): it then ran under the PREVIOUS call's tail,
+        so level 1 is not speculated)."""
         p = "encoder."
         side = self.side_stream(xyz.device)
         ready = {}
+        speculate = side is not None and pyramid is None
         if side is not None:
             main = torch.cuda.current_stream(xyz.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                pcs = [xyz]
-                sel1 = None
-                for lvl, npoint in enumerate((2048, 512, 256, 64), start=1):
-                    pts, sel = self.fps_gather(pcs[-1], npoint, return_idx=True)
-                    pcs.append(pts)
-                    sel1 = sel if lvl == 1 else sel1
-                    ready[lvl] = torch.cuda.Event()
-                    ready[lvl].record(side)
-            _, pc1, pc2, pc3, pc4 = pcs
-            for t in (pc1, pc2, pc3, pc4, sel1):  # allocated on the side stream, consumed on the main stream
-                t.record_stream(main)
+            if pyramid is None:
+                side.wait_stream(main)
+                pyramid = self.sample_pyramid(xyz, side)
+            (_, pc1, pc2, pc3, pc4), sel1, ready = pyramid
         else:
             pc1, sel1 = self.fps_gather(xyz, 2048, return_idx=True)
             pc2 = self.fps_gather(pc1, 512)
@@ -236,7 +248,7 @@ class MoCoPCI(nn.Module):
         idx0 = ops.backend().knn(xyz, xyz, 32)
         f0 = self.pointconv(p + "level0", xyz, xyz, f0, idx=idx0)
         f0_1 = self.conv1d_block(f0, p + "level0_1")
-        if side is not None:
+        if speculate:
             # The main stream would now wait ~0.6 ms for the level-1 sampling.  Level 1 is a PointConvD whose centres are
             # SAMPLED points of xyz and whose neighbours are rows of the level-0 self search (sampled_neighbours), so its
             # output for every candidate centre can be computed before the sample is known -- 4x the work, on an otherwise
@@ -702,20 +714,39 @@ class MoCoPCI(nn.Module):
             flows_b.append([p2[l] + lv[l][B:, 2 - i] for i in range(3)])
         return flows_f, flows_b, out_lst
 
-    def forward(self, xyz1, xyz2, gt=None, t=None, train=False):
+    def forward(self, xyz1, xyz2, gt=None, t=None, train=False, inputs_ready=None):
         """MoCoPCI.forward (mocopci.py:1069-1097): xyz1, xyz2 (B,3,N) -> out_lst, 3 x (B,N,3).
         train=True: (frames_lst_f, frames_lst_b, gt_frame, out_lst) as the reference returns, computed with autograd enabled so
         that train.py:135-160's loss can be back-propagated: gradients reach every parameter through the fused kernels
         (mocopci_amd.grad).  gt: 3 x (B,3,N) as train.py:125-126 passes it.  Normalisation layers use their running statistics
         and dropout / stochastic depth are not applied in either mode (the reference's nn.Dropout(0.05) / DropPath(0.04) draw from
-        the device RNG and cannot be pinned; a fine-tuning run from a checkpoint behaves like the reference's net.eval() graph)."""
+        the device RNG and cannot be pinned; a fine-tuning run from a checkpoint behaves like the reference's net.eval() graph).
+        inputs_ready (inference, optional): a torch.cuda.Event after which xyz1 / xyz2 are complete (e.g. recorded by the loader's
+        copy stream).  The furthest-point-sampling pyramid of the encoder depends on nothing but the inputs and is a 1.5 ms chain
+        of latency-bound kernels on 16 CUs; with the event it is issued on the side stream behind THAT event instead of behind
+        the caller's whole stream, so in a loop of forwards it runs under the tail of the previous call (pipelining of
+        consecutive batches; a single isolated call is unchanged).  Without it the stream-ordered default applies."""
         B = xyz1.shape[0]
-        xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
         if not train:
             with torch.no_grad(), ops.backend().cloud_scope():
+                pyramid = None
+                side = self.side_stream(xyz1.device) if inputs_ready is not None else None
+                if side is not None:
+                    main = torch.cuda.current_stream(xyz1.device)
+                    side.wait_event(inputs_ready)
+                    with torch.cuda.stream(side):
+                        xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
+                        laid_out = torch.cuda.Event()
+                        laid_out.record(side)
+                    xyz.record_stream(main)
+                    pyramid = self.sample_pyramid(xyz, side)
+                    main.wait_event(laid_out)
+                else:
+                    xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
                 self._early = Early(self, xyz.device)
-                pcs, feats = self.run_encoder(xyz, self._early)
+                pcs, feats = self.run_encoder(xyz, self._early, pyramid=pyramid)
                 return self.run_decoder(pcs, feats, B)
+        xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
         self._live = {**dict(self.named_parameters()), **dict(self.named_buffers())}
         try:
             with torch.enable_grad(), ops.backend().cloud_scope():
