@@ -38,6 +38,7 @@ SPLIT_PRODUCTS = 6              # bf16 partial products per fp32 product on the 
 NPOINTS = 8192
 B_PER_GPU = 8
 FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock", "mlp")
+HEADLINE = "fusion"  # the single kernel symbol with the most time on a step's critical (main) stream
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
 
 NAMES = {
@@ -195,6 +196,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="do not pipeline the input-only sampling pyramid across consecutive steps")
+    ap.add_argument("--streams", type=int, default=1, help="steps in flight: consecutive steps issued round-robin on this many HIP streams "
+                                                            "(measured: 2-3 give 0-10 %% depending on how the runtime maps the ~15 streams onto its 4 "
+                                                            "hardware queues, not reproducibly; more hardware queues make it worse)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -233,15 +237,33 @@ def main():
         inputs_ready = torch.cuda.Event()
         inputs_ready.record()
 
+    # Steps in flight (--streams, default 1).  Consecutive steps are independent and a single step leaves much of the chip idle
+    # for stretches (FPS chains on 16-24 CUs, the small-kernel stages of the lower pyramid levels), so they can be issued
+    # round-robin on a few HIP streams, each with its own side streams.  Measured gain 0-10 %, not reproducible from run to run
+    # (it depends on how the runtime maps the streams onto its hardware queues), hence not the default.
+    n_streams = 1 if args.serial else max(1, args.streams)
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream(dev)]
+    for ln in lanes:
+        ln.wait_stream(torch.cuda.current_stream(dev))
+    counter = [0]
+
     def step():
-        out = net(x1, x2, inputs_ready=inputs_ready)   # 3 x (B,N,3)
-        return shard.gather_frames(out, world)  # (world*B,3,N,3) on every rank; no-op view for world == 1
+        ln = lanes[counter[0] % n_streams]
+        counter[0] += 1
+        with torch.cuda.stream(ln):
+            out = net(x1, x2, inputs_ready=inputs_ready)   # 3 x (B,N,3)
+            return shard.gather_frames(out, world)  # (world*B,3,N,3) on every rank; no-op view for world == 1
 
     for _ in range(args.warmup):
         step()
     calls = log_call_shapes(ops.backend(), step)
+    for _ in range(n_streams - 1):  # every lane has run at least once before the clock starts
+        step()
 
-    ops.prof_enable(FAMILIES)
+    # Inside the timed region only the headline kernel is bracketed by hipEvents (two records per step).  Bracketing all nine
+    # families (~45 launches per step) costs ~0.4 ms per step of stream time and serialises the steps in flight, so the other
+    # families are timed in a second, instrumented pass right after the timed region (same process, same inputs, one stream).
+    ops.prof_enable(() if os.environ.get("MCP_BENCH_NOPROF") == "1" else (HEADLINE,))  # MCP_BENCH_NOPROF: A/B of the event overhead only
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -252,6 +274,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    headline_timed = ops.prof_collect(HEADLINE)
+    inst_steps = min(args.steps, 10)
+    ops.prof_enable(FAMILIES)
+    for _ in range(inst_steps):
+        net(x1, x2)                      # current stream, stream-ordered: every kernel alone with its own step
+    torch.cuda.synchronize()
     timed = {k: ops.prof_collect(k) for k in FAMILIES}
     ops.prof_enable(None)
     if world > 1:
@@ -284,6 +312,7 @@ def main():
                    "npoints": NPOINTS, "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world,
                    "parallelism": f"sequence-sharded x{world}, final all_gather over RCCL" if world > 1 else "single GPU",
                    "weights": "deterministic by-name synthetic, eval mode",
+                   "steps_in_flight": n_streams,
                    "step_pipelining": "off (--serial)" if args.serial else "the furthest-point-sampling pyramid of step k+1 (input-only, side stream) "
                                       "is issued behind the inputs' ready event and overlaps the tail of step k; all work of every step is inside the timed region",
                    "arithmetic": "fp32 values throughout; the fused MLP layers form each fp32 product from six bf16 MFMA partial products of an "
@@ -298,7 +327,9 @@ def main():
         result["parity"] = par
 
     pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}
-    entries = roofline_entries(timed, calls, args.steps, pmc)
+    entries = roofline_entries(timed, calls, inst_steps, pmc)
+    for e in entries:
+        e["timed_in"] = f"instrumented pass of {inst_steps} stream-ordered steps right after the timed region (one step in flight)"
     # Dominant kernel = the single kernel symbol with the most time on the step's critical (main) stream.  The FPS chains run
     # beside it on a side stream (mocopci_amd/model.py) and the KNN family is a dozen launches of several kernel symbols
     # (pruned / queue / small x K variants, none above 0.35 ms), so both are listed under roofline_others; among the
@@ -306,7 +337,14 @@ def main():
     single = sorted((e for e in entries if not e["kernel"].startswith(("fps_", "knn_pruned"))), key=lambda e: -e["kernel_ms_per_step"])
     rest = [e for e in entries if e["kernel"].startswith(("knn_pruned", "fps_"))]
     if single:
-        result["roofline"] = single[0]
+        # the headline kernel as measured INSIDE the timed region (with the other steps in flight sharing the chip); the same
+        # kernel alone on the chip (instrumented pass) is kept beside it
+        alone = single[0]
+        live = (roofline_entries({k: (headline_timed if k == HEADLINE else (0, 0.0)) for k in FAMILIES}, calls, args.steps, pmc) or [dict(alone)])[0]
+        live["timed_in"] = f"the timed region ({n_streams} step(s) in flight)"
+        live["alone"] = {k: alone[k] for k in ("achieved", "frac", "avg_launch_us", "kernel_ms_per_step", "timed_in")}
+        assert alone["kernel"] == NAMES[HEADLINE]
+        result["roofline"] = live
         result["roofline_others"] = single[1:] + rest
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

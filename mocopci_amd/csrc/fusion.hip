@@ -287,7 +287,12 @@ MCP_EXPORT int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2
     if (nb != NB) return MCP_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)b * n;
-    const unsigned grid = (unsigned)min((total + WAVES - 1) / WAVES, 1024LL);
+    // 8 rounds of workgroups over the 512 resident slots rather than 2: the points are dealt out statically, so when another
+    // stream's kernels hold some CUs (the next step's FPS chains take 16-24 of them, workgroups that leave no room for one of
+    // these) a 2-round grid ends on the slowest slots -- measured 1.63 ms in the step against 1.34 ms alone; 8 rounds let the
+    // dispatcher rebalance (1.38 ms in the step) and cost nothing alone (the weight staging is ~1 % of a 48-point workgroup).
+    static const long long grid_cap = [] { const char *v = getenv("MCP_FUSION_GRID"); return (long long)(v && *v ? atoi(v) : 4096); }();
+    const unsigned grid = (unsigned)min((total + WAVES - 1) / WAVES, grid_cap);
     static const bool f32_mfma = [] { const char *v = getenv("MCP_FUSION_F32_MFMA"); return v && *v == '1'; }();
     mcp_prof_begin(MCP_KERNEL_FUSION, s);
     if (f32_mfma) {

@@ -25,9 +25,17 @@ MCP_DIST_DIRECT = 1
 
 
 def _call(name, ref_tensor, *args):
-    lib = _lib.load()
-    with torch.cuda.device(ref_tensor.device):
-        _lib.check(getattr(lib, name)(*args, _lib.stream()))
+    """One library call on torch's current stream of the tensor's device.  The device guard is taken only when the tensor lives
+    on another device than the current one (the guard costs more host time than the launch itself)."""
+    fn = getattr(_lib.load(), name)
+    dev = ref_tensor.device
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        rc = fn(*args, torch.cuda.current_stream().cuda_stream)
+    else:
+        with torch.cuda.device(dev):
+            rc = fn(*args, torch.cuda.current_stream().cuda_stream)
+    if rc:
+        _lib.check(rc)
 
 
 def _group_rows_fwd(points, idx):
