@@ -330,22 +330,18 @@ def main():
     entries = roofline_entries(timed, calls, inst_steps, pmc)
     for e in entries:
         e["timed_in"] = f"instrumented pass of {inst_steps} stream-ordered steps right after the timed region (one step in flight)"
-    # Dominant kernel = the single kernel symbol with the most time on the step's critical (main) stream.  The FPS chains run
-    # beside it on a side stream (mocopci_amd/model.py) and the KNN family is a dozen launches of several kernel symbols
-    # (pruned / queue / small x K variants, none above 0.35 ms), so both are listed under roofline_others; among the
-    # one-symbol families the one with the largest time per launch-set leads.
-    single = sorted((e for e in entries if not e["kernel"].startswith(("fps_", "knn_pruned"))), key=lambda e: -e["kernel_ms_per_step"])
-    rest = [e for e in entries if e["kernel"].startswith(("knn_pruned", "fps_"))]
-    if single:
-        # the headline kernel as measured INSIDE the timed region (with the other steps in flight sharing the chip); the same
-        # kernel alone on the chip (instrumented pass) is kept beside it
-        alone = single[0]
+    # Headline = the single kernel symbol with the most time on the step's critical (main) stream: the fusion kernel (HEADLINE;
+    # profiles/r02_step_by_queue.txt).  The FPS chains run beside the main stream on a side stream and the KNN family is a dozen
+    # launches of several kernel symbols (pruned / queue / small x K variants, none above 0.35 ms): both under roofline_others.
+    alone = next((e for e in entries if e["kernel"] == NAMES[HEADLINE]), None)
+    if alone is not None:
+        # the headline kernel as measured INSIDE the timed region (beside whatever else is on the chip: the next step's FPS
+        # chains); the same kernel alone on the chip (instrumented pass) is kept beside it
         live = (roofline_entries({k: (headline_timed if k == HEADLINE else (0, 0.0)) for k in FAMILIES}, calls, args.steps, pmc) or [dict(alone)])[0]
         live["timed_in"] = f"the timed region ({n_streams} step(s) in flight)"
         live["alone"] = {k: alone[k] for k in ("achieved", "frac", "avg_launch_us", "kernel_ms_per_step", "timed_in")}
-        assert alone["kernel"] == NAMES[HEADLINE]
         result["roofline"] = live
-        result["roofline_others"] = single[1:] + rest
+        result["roofline_others"] = sorted((e for e in entries if e is not alone), key=lambda e: -e["kernel_ms_per_step"])
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
