@@ -37,7 +37,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 SPLIT_PRODUCTS = 6              # bf16 partial products per fp32 product on the split path (mocopci_amd/csrc/mfma_split.h)
 NPOINTS = 8192
 B_PER_GPU = 8
-FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock", "mlp")
+FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock", "mlp", "linear")
 HEADLINE = "fusion"  # the single kernel symbol with the most time on a step's critical (main) stream
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
 
@@ -51,6 +51,7 @@ NAMES = {
     "attention": "attention_small_kernel<8|16> / attention_wide_kernel<32|256> (mcp_attention_small, mcp_attention_wide)",
     "ptblock": "ptblock_kernel (mcp_ptblock_attention)",
     "mlp": "mlp2_kernel (mcp_mlp2)",
+    "linear": "linear_kernel (mcp_linear)",
 }
 NOTES = {
     "fps": "achieved/frac = SURVEY 8(d)'s figure: bytes of the REFERENCE'S streaming formulation B*(M-1)*20*N over kernel time -- NOT a "
@@ -68,6 +69,7 @@ NOTES = {
     "attention": "4*BF*H*Nq*Nk*hd flop; S = QK^T on the f32-input MFMA, softmax and (head dims 8/16) P.V on the VALU",
     "ptblock": "B*N*16*2*(3*64 + 3*64^2) flop; the three 64x64 layers on the split-bf16 path",
     "mlp": "2*rows*(C*H + H*C_out) flop of the fused Mlp_T / flow-head blocks on the split-bf16 path, weights streamed through LDS",
+    "linear": "tall per-point Linear layers with fused activation / residual: bytes read + written, 4*rows*(K+n) (memory-bound by design)",
 }
 
 
@@ -91,6 +93,8 @@ def algorithmic_work(kernel, calls):
         return sum(b * n * 16 * 2 * (3 * 64 + 3 * 64 * 64) for (b, n) in calls), "flops"
     if kernel == "mlp":
         return sum(2 * rows * (c * h + h * co) for (rows, c, h, co) in calls), "flops"
+    if kernel == "linear":
+        return sum(4 * rows * (k + n) for (rows, k, n) in calls), "bytes"
     raise KeyError(kernel)
 
 
@@ -99,7 +103,7 @@ def log_call_shapes(be, step):
     3-NN searches inside interp3 / interp3_search reach the timer through be.knn, so only be.knn records them; the fused
     small-level mcp_interp3 call (its own KNN launch inside the library) records here."""
     calls = {k: [] for k in FAMILIES}
-    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "ptblock_attention", "mlp2")
+    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "ptblock_attention", "mlp2", "linear")
     orig = {n: getattr(be, n) for n in names}
 
     def wrap(name, rec):
@@ -121,6 +125,9 @@ def log_call_shapes(be, step):
     be.pointconv_agg = wrap("pointconv_agg", lambda sx, nx, sp, *a: calls["pointconv"].append((nx.shape[0], nx.shape[1], sp.shape[2])))
     be.attention = wrap("attention", lambda q, kv, h, **kw: calls["attention"].append((q.shape[0], h, q.shape[1], kv.shape[1], q.shape[2] // h)))
     be.ptblock_attention = wrap("ptblock_attention", lambda xyz, q, *a: calls["ptblock"].append((q.shape[0], q.shape[1])))
+    be.linear = wrap("linear", lambda xs, w, *a, **k: calls["linear"].append(((xs[0] if isinstance(xs, (tuple, list)) else xs).numel()
+                                                                               // (xs[0] if isinstance(xs, (tuple, list)) else xs).shape[-1],
+                                                                               w.shape[1], w.shape[0])))
     be.mlp2 = wrap("mlp2", lambda x, w1, b1, w2, *a, **k: calls["mlp"].append((x.numel() // x.shape[-1], w1.shape[1], w1.shape[0], w2.shape[0])))
     try:
         step()

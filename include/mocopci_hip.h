@@ -224,6 +224,18 @@ int mcp_attention_wide(int bf, int nq, int nk, int heads, int hd, const float *q
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);
 
+/* Per-point Linear (1x1 convolution) with fused epilogue for the tall-skinny shapes of the caller graph (Conv1d wrapper
+ * mocopci.py:1111-1127, the Linear layers of :438-468 / :821-1059, and the concatenations in front of them, :186-187, :846-847):
+ *     out[r, 0:n] = act( sum_i W_i . x_i[r] + b ) [+ res[r]],   act(v) = v > 0 ? v : slope * v   (slope 1: none, 0: ReLU, 0.1: LeakyReLU)
+ * The input is given as nseg <= 3 pieces x[i] (rows, k_seg[i]) with row strides x_stride[i] (floats; 16-byte aligned rows,
+ * k_seg[i] a multiple of 4): the pieces of what the reference concatenates, read in place.  W is (n, sum k_seg) row-major over
+ * the concatenated K axis; n <= 128, or 129..192, or 193..256.  mcp_linear_pack prepares (W, b) once into
+ * mcp_linear_packed_floats(n, nseg, k_seg) caller-owned floats (0 = unsupported shape); b may be NULL. */
+int mcp_linear_packed_floats(int n, int nseg, const int *k_seg);
+int mcp_linear_pack(int n, int nseg, const int *k_seg, const float *w, const float *b, float *packed, mcp_stream_t stream);
+int mcp_linear(long long rows, int n, int nseg, const float *const *x, const int *x_stride, const int *k_seg, float slope,
+               const float *packed, const float *res, int res_stride, float *out, int out_stride, mcp_stream_t stream);
+
 /* Fused two-layer per-point MLP (Mlp_T of Multi_Frame_Att, mocopci.py:1558-1565 inside :551-575, and the flow heads
  * trans_block / trans_block_2 -> mapping_xyz, :566-567 / :510-511):
  *     out[r, 0:cout] = (res ? res[r] : 0) + b2 + W2 . act(W1 . x[r] + b1),   act(v) = v > 0 ? v : slope * v   (PReLU with one slope)
@@ -272,6 +284,7 @@ int mcp_emd(int b, int n, int m, const float *xyz1, const float *xyz2, float *ma
 #define MCP_KERNEL_ATTENTION 9
 #define MCP_KERNEL_PTBLOCK 10
 #define MCP_KERNEL_MLP 11
+#define MCP_KERNEL_LINEAR 12
 int mcp_prof_enable(int kernel_mask);
 int mcp_prof_collect(int kernel_id, int *launches, float *total_ms);
 

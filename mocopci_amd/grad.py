@@ -121,6 +121,15 @@ def attention_twin(q, kv, heads, scale):
     return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
 
 
+def linear_twin(xs, w, b, slope, res):
+    """Linear over the concatenation of the pieces + one-slope activation + residual (Conv1d wrapper, mocopci.py:1111-1127)."""
+    x = torch.cat(list(xs), dim=-1) if isinstance(xs, (tuple, list)) else xs
+    y = F.linear(x, w, b)
+    if slope != 1.0:
+        y = torch.where(y > 0, y, y * slope)
+    return y if res is None else y + res
+
+
 def mlp2_twin(x, res, w1, b1, w2, b2, slope):
     """Two-layer per-point MLP with a one-slope PReLU (Mlp_T, mocopci.py:1558-1565, with its affine neighbours folded in)."""
     hid = F.linear(x, w1, b1)

@@ -143,12 +143,23 @@ class MoCoPCI(nn.Module):
     def Bv(self, name):
         return self._params().get(name + ".bias")
 
-    def lin(self, x, name):
-        return F.linear(x, self.W(name), self.Bv(name))
+    def lin(self, x, name, slope=1.0, res=None):
+        """Linear / 1x1 conv `name` over the last axis with a one-slope activation (1.0 = none) and a residual: ONE kernel
+        (ops.linear) where the backend takes the shape -- the tall per-point layers -- and the BLAS chain otherwise."""
+        w, b = self.W(name), self.Bv(name)
+        be = ops.backend()
+        if be.linear_supported(x, w.shape[0]):
+            packed = None if self._live is not None else self.derived(("lin_pack", be.name, name, x.shape[-1]),
+                                                                      lambda: be.linear_pack(w, b, [x.shape[-1]]))
+            return be.linear(x, w, b, slope, res, packed=packed)
+        y = F.linear(x, w, b)
+        if slope != 1.0:
+            y = F.leaky_relu(y, slope)
+        return y if res is None else y + res
 
     def conv1d_block(self, x, name):
         """Conv1d wrapper of the reference (mocopci.py:1111-1127): 1x1 conv + LeakyReLU(0.1)."""
-        return leaky(self.lin(x, name + ".composed_module.0"))
+        return self.lin(x, name + ".composed_module.0", slope=LEAKY)
 
     def bn_eval(self, x, name, eps):
         """BatchNorm in eval mode on a channel-last tensor: one fused multiply-add with cached (scale, shift)."""
@@ -171,7 +182,7 @@ class MoCoPCI(nn.Module):
             idx = be.knn(new_xyz, s_xyz, nsample)
         wn = [t for i in range(3) for t in (self.W(f"{prefix}.weightnet.mlp_convs.{i}"), self.Bv(f"{prefix}.weightnet.mlp_convs.{i}"))]
         agg = be.pointconv_agg(s_xyz, new_xyz, s_points.contiguous(), idx, *wn)      # (B,S,(3+D)*8)
-        return leaky(self.lin(agg, prefix + ".linear"))
+        return self.lin(agg, prefix + ".linear", slope=LEAKY)
 
     def fps_gather(self, xyz, npoint, return_idx=False):
         """furthest_point_sample + index_points_gather (mocopci.py:1378-1379)."""
@@ -430,8 +441,7 @@ class MoCoPCI(nn.Module):
             B, Fr = x.shape[0], 1
         o = ops.backend().attention(self.lin(xn, a + ".q").reshape(B * Fr, N, C), self.lin(xr, a + ".kv").reshape(B * Fr, N, 2 * C),
                                     heads)                                         # (B*3,N,C)
-        o = self.lin(o.reshape(B, Fr, N, C), a + ".proj")
-        xn = xn + o
+        xn = self.lin(o.reshape(B, Fr, N, C), a + ".proj", res=xn)                 # xn + proj(attention), mocopci.py:559
         x = self.mlp_t(prefix + ".mlp", xn, res=x, bn=(prefix + ".norm2", 1e-5))   # x + mlp(norm2(xn)), mocopci.py:561-563
         if not feats:  # flows only: trans_block.fc2 and mapping_xyz collapse into one (4C -> 3) map
             return None, self.mlp_t(prefix + ".trans_block", x, tail=prefix + ".mapping_xyz")
@@ -699,7 +709,7 @@ class MoCoPCI(nn.Module):
             dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel))
             shape = self.transformer_block(m + "shape1", dfeat, down)
             upf = ops.backend().interp3(warped, down, shape)
-        refine = self.lin(F.relu(self.lin(upf, m + "pred.0")), m + "pred.2")       # (3B,N,3)
+        refine = self.lin(self.lin(upf, m + "pred.0", slope=0.0), m + "pred.2")    # (3B,N,3): Linear, ReLU, Linear
         final = self.fusion(warped, refine, idx_self=idx_self)
         out_lst = [final[:B], final[B:2 * B], final[2 * B:]]
         if not train:

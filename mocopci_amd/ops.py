@@ -370,6 +370,75 @@ class HipBackend:
               float(scale), out.data_ptr(), C)
         return out
 
+    # ---- per-point Linear with fused epilogue (csrc/linear.hip) ----
+    @staticmethod
+    def _pieces(xs):
+        """The input pieces as 2-D row views (rows, k_i) with unit channel stride, 16-byte aligned rows; None if one of them
+        cannot be read in place."""
+        out = []
+        for t in (xs if isinstance(xs, (tuple, list)) else (xs,)):
+            k = t.shape[-1]
+            v = t.reshape(-1, k) if t.is_contiguous() else (t if t.dim() == 2 else None)
+            if v is None and t.stride(-1) == 1:  # a last-axis slice of a contiguous tensor: rows keep the parent's stride
+                lead = t.shape[:-1]
+                st = t.stride()
+                ok = all(st[i] == st[i + 1] * lead[i + 1] for i in range(len(lead) - 1))
+                v = t.as_strided((t.numel() // k, k), (st[-2], 1)) if ok else None
+            if v is None or v.stride(1) != 1 or v.stride(0) % 4 or v.data_ptr() % 16 or k % 4 or v.dtype != torch.float32 or not v.is_cuda:
+                return None
+            out.append(v)
+        return out
+
+    def linear_supported(self, xs, n):
+        """Whether linear() takes this call.  Beyond what the kernel can do, a shape policy: the fused kernel beats the BLAS
+        chain for tall inputs with moderate K (tools/linear_ab.py, MI355X: 1.4-1.9x at rows >= 32768, K <= 280, e.g. 58 -> 32 us
+        for 196608 x 32 -> 64 + LeakyReLU) and loses for few rows (one 256-row workgroup per 8 waves: 2048-8192 rows do not cover
+        the chip) and for long K at narrow N (K = 536: 17 chunk hand-offs of 24 MFMAs each), which stay on the library."""
+        if self._NO_LINEAR:
+            return False
+        ps = self._pieces(xs)
+        if ps is None or len(ps) > 3 or len({p.shape[0] for p in ps}) != 1:
+            return False
+        if ps[0].shape[0] < 16384 or sum(p.shape[1] for p in ps) > 320 or n > 192:
+            return False
+        ks = (ctypes.c_int * len(ps))(*[p.shape[1] for p in ps])
+        return _lib.load().mcp_linear_packed_floats(n, len(ps), ks) != 0
+
+    _NO_LINEAR = os.environ.get("MCP_NO_LINEAR", "0") == "1"
+
+    def linear_pack(self, w, b, ks):
+        """Operand image of one Linear whose K axis is the concatenation of pieces of widths ks (split once per layer)."""
+        n = w.shape[0]
+        kk = (ctypes.c_int * len(ks))(*ks)
+        nf = _lib.load().mcp_linear_packed_floats(n, len(ks), kk)
+        if nf == 0:
+            raise RuntimeError(f"linear does not support n={n}, pieces={list(ks)}")
+        packed = torch.empty((nf,), dtype=torch.float32, device=w.device)
+        _call("mcp_linear_pack", w, n, len(ks), kk, _lib.fptr(w.contiguous()), None if b is None else _lib.fptr(b.contiguous()), _lib.fptr(packed))
+        return packed
+
+    def linear(self, xs, w, b=None, slope=1.0, res=None, packed=None):
+        """act(W [x_0 | x_1 | x_2] + b) [+ res] over the last axis: xs one tensor or up to three pieces of a concatenation (read in
+        place, column slices allowed); act(v) = v > 0 ? v : slope v (1.0: none, 0.1: LeakyReLU, 0: ReLU, a PReLU slope).
+        One kernel instead of cat + GEMM + activation + add.  Differentiable.  packed: linear_pack(w, b, widths) if kept."""
+        def fused(xs_, w_, b_, slope_, res_):
+            ps = self._pieces(xs_)
+            ks = [p.shape[1] for p in ps]
+            pk = packed if packed is not None else self.linear_pack(w_, b_, ks)
+            rows, n = ps[0].shape[0], w_.shape[0]
+            first = xs_[0] if isinstance(xs_, (tuple, list)) else xs_
+            out = torch.empty((rows, n), dtype=torch.float32, device=first.device)
+            r2 = None if res_ is None else res_.reshape(rows, n).contiguous()
+            xp = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+            st = (ctypes.c_int * len(ps))(*[p.stride(0) for p in ps])
+            kk = (ctypes.c_int * len(ps))(*ks)
+            _call("mcp_linear", first, rows, n, len(ps), xp, st, kk, float(slope_), _lib.fptr(pk), None if r2 is None else _lib.fptr(r2), n,
+                  _lib.fptr(out), n)
+            return out.reshape(*first.shape[:-1], n)
+        if isinstance(xs, (tuple, list)) and grad.wants_grad(*xs, w, b, res):
+            return grad.linear_twin(xs, w, b, slope, res)  # training: plain autograd over the concatenation
+        return grad.run(fused, grad.linear_twin, xs, w, b, slope, res)
+
     def mlp2_pack(self, w1, b1, w2, b2):
         """Operand image of one two-layer MLP for mlp2 (split once; do this once per block)."""
         hidden, cin = w1.shape
@@ -438,7 +507,7 @@ def set_backend(b):
 
 
 # ---- instrumentation passthrough (bench.py) ----
-KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7, "pointconv": 8, "attention": 9, "ptblock": 10, "mlp": 11}
+KERNEL_IDS = {"fps": 1, "knn": 2, "group_rows": 3, "interp3": 4, "knn_cosine": 5, "fusion": 6, "cross": 7, "pointconv": 8, "attention": 9, "ptblock": 10, "mlp": 11, "linear": 12}
 
 
 def prof_enable(kernel_names):

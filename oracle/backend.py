@@ -128,6 +128,21 @@ class OracleBackend:
     def mlp2_pack(self, w1, b1, w2, b2):
         return None
 
+    def linear_supported(self, xs, n):
+        return True
+
+    def linear_pack(self, w, b, ks):
+        return None
+
+    def linear(self, xs, w, b=None, slope=1.0, res=None, packed=None):
+        """Conv1d wrapper of the reference (mocopci.py:1111-1127) generalised: Linear over the concatenated pieces, one-slope
+        activation, residual."""
+        x = torch.cat(list(xs), dim=-1) if isinstance(xs, (tuple, list)) else xs
+        y = torch.nn.functional.linear(x, w, b)
+        if slope != 1.0:
+            y = torch.where(y > 0, y, y * slope)
+        return y if res is None else y + res
+
     def mlp2(self, x, w1, b1, w2, b2, slope, res=None, packed=None):
         """Linear, one-slope PReLU, Linear (+ residual): Mlp_T with its affine neighbours folded in, mocopci.py:1558-1565."""
         hid = torch.nn.functional.linear(x, w1, b1)

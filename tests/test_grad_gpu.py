@@ -132,6 +132,14 @@ def test_mlp2_gradients(cin, hidden, cout):
                   [x, res, *w, slope], names=["x", "res", "w1", "b1", "w2", "b2", "slope"])
 
 
+def test_linear_gradients():
+    x, res = rnd(96, 20000, 64), rnd(97, 20000, 32)
+    w, b = rnd(98, 32, 64, scale=0.125), rnd(99, 32, scale=0.1)
+    ob, be = OracleBackend(), ops.backend()
+    compare_grads(lambda a, r, ww, bb: be.linear(a, ww, bb, 0.1, r), lambda a, r, ww, bb: ob.linear(a, ww, bb, 0.1, r), [x, res, w, b],
+                  names=["x", "res", "w", "b"])
+
+
 def test_chamfer_gradients():
     x, y = cloud(80, 2, 500), cloud(81, 2, 700)
     ob, be = OracleBackend(), ops.backend()

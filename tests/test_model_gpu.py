@@ -115,8 +115,10 @@ def test_forward_under_inference_mode():
 
 def test_inputs_ready_event_pipelines_without_changing_results():
     """forward(inputs_ready=event): the encoder's sampling pyramid is issued behind the event instead of behind the caller's stream
-    (it then runs under the previous call's tail).  Same kernels on the same data: the frames are bit-identical to the
-    stream-ordered call, also when several calls are queued back to back and when the inputs change between calls."""
+    (it then runs under the previous call's tail) and level 1 is computed for the sampled centres only instead of speculatively
+    for all candidates.  Several calls queued back to back, inputs changing between calls: every call reproduces itself bit for
+    bit, and agrees with the stream-ordered call within the displacement budgets (the speculative path multiplies 4x the rows,
+    so its BLAS kernels tile differently: not bit-identical)."""
     from mocopci_amd import synth
     net = hc.build_model("cuda:0")
     batches = [synth.make_batch(2, 2, 8192, device="cuda:0", first_sample=s)[:2] for s in (0, 2)]
@@ -127,5 +129,7 @@ def test_inputs_ready_event_pipelines_without_changing_results():
     got = [net(x1, x2, inputs_ready=ev) for x1, x2 in batches * 2]  # four calls in flight
     torch.cuda.synchronize()
     for k, frames in enumerate(got):
-        for u, v in zip(frames, want[k % 2]):
-            assert torch.equal(u, v)
+        for j, (u, v) in enumerate(zip(frames, want[k % 2])):
+            assert torch.equal(u, got[k % 2][j])                                   # the same call again: same bits
+            elem, pts, worst, mse = hc.frame_deviation(u.cpu().numpy(), v.cpu().numpy())
+            assert elem <= 0.02 and pts <= hc.POINT_BUDGET and worst <= hc.MAX_DISP_BUDGET and mse <= hc.MSE_BUDGET, (k, j, elem, pts, worst, mse)

@@ -564,3 +564,25 @@ def test_mlp2_matches_unfused_oracle(cin, hidden, cout, rows, with_res):
     torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
     got2 = be.mlp2(x.contiguous().to(DEV), *dw, 0.25, res=None if res is None else res.to(DEV), packed=be.mlp2_pack(*dw))
     assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("rows,ks,n,slope,with_res", [(20000, (64,), 64, 0.1, False), (16390, (280,), 32, 0.1, False), (17000, (64, 64, 64), 64, 1.0, True),
+                                                      (16384, (32,), 192, 0.0, False), (33000, (128,), 100, 0.25, True)])
+def test_linear_matches_unfused_oracle(rows, ks, n, slope, with_res):
+    """Fused per-point Linear (Conv1d wrapper mocopci.py:1111-1127 + the concatenation in front of it) against the oracle backend's
+    cat - Linear - activation - residual; one piece is read through a row stride (a column slice of a wider tensor)."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(rows + n)
+    wide = torch.randn(rows, ks[0] + 12, generator=g)
+    xs = [wide[:, 4:4 + ks[0]]] + [torch.randn(rows, k, generator=g) for k in ks[1:]]
+    w, b = torch.randn(n, sum(ks), generator=g) / sum(ks) ** 0.5, torch.randn(n, generator=g) * 0.1
+    res = torch.randn(rows, n, generator=g) if with_res else None
+    want = OracleBackend().linear(xs, w, b, slope, res)
+    be = ops.backend()
+    wd = wide.to(DEV)
+    xd = [wd[:, 4:4 + ks[0]]] + [t.to(DEV) for t in xs[1:]]
+    assert be.linear_supported(xd, n)
+    got = be.linear(xd if len(xd) > 1 else xd[0], w.to(DEV), b.to(DEV), slope, None if res is None else res.to(DEV))
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
+    # shapes outside the policy are declined (the caller then takes the BLAS chain)
+    assert not be.linear_supported(xd[0][:2048], n) and not be.linear_supported(torch.empty(20000, 600, device=DEV), 64)

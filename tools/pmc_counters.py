@@ -33,6 +33,7 @@ FAMILIES = {  # name -> kernel-name substrings
     "attention": ("attention_small_kernel", "attention_kernel"),
     "ptblock": ("ptblock_kernel",),
     "mlp": ("mlp2_kernel",),
+    "linear": ("linear_kernel",),
     "group_rows": ("group_rows_kernel",),
     "interp3": ("interp3_",),
     "dense": ("dense_",),
