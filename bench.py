@@ -121,7 +121,7 @@ def log_call_shapes(be, step):
     be.interp3 = wrap("interp3", rec_interp3)
     be.knn_cosine = wrap("knn_cosine", lambda q, r, k, **kw: calls["knn_cosine"].append((q.shape[0], q.shape[1], r.shape[1], q.shape[2])))
     be.fusion_mlp = wrap("fusion_mlp", lambda p1, *a: calls["fusion"].append((p1.shape[0], p1.shape[1])))
-    be.cross_volume = wrap("cross_volume", lambda x1, x2, f1, *a: calls["cross"].append((f1.shape[0], f1.shape[1], f1.shape[2])))
+    be.cross_volume = wrap("cross_volume", lambda x1, x2, f1, *a, **k: calls["cross"].append((x1.shape[0], x1.shape[1], f1.shape[2])))
     be.pointconv_agg = wrap("pointconv_agg", lambda sx, nx, sp, *a: calls["pointconv"].append((nx.shape[0], nx.shape[1], sp.shape[2])))
     be.attention = wrap("attention", lambda q, kv, h, **kw: calls["attention"].append((q.shape[0], h, q.shape[1], kv.shape[1], q.shape[2] // h)))
     be.ptblock_attention = wrap("ptblock_attention", lambda xyz, q, *a: calls["ptblock"].append((q.shape[0], q.shape[1])))

@@ -190,12 +190,15 @@ int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int
  * The layer's weights -- wpos (D,3), bpos (D) = the Conv2d 3->D; wmlp (D,D), bmlp (D) = the single Conv2d D->D of
  * the mlp list (every layer MoCoPCI builds has exactly one) -- are packed ONCE per layer by mcp_cross_pack into
  * the MFMA-operand image (mcp_cross_packed_floats(D) floats, 16-byte aligned, caller-owned).  D in {64,128}, k = 32.  Neighbour lists: idx (B,N1,32), or with idx2 != NULL
- * the 16 + 16 halves as two (B,N1,16) lists (feature-space neighbours, then coordinate-space neighbours). */
+ * the 16 + 16 halves as two (B,N1,16) lists (feature-space neighbours, then coordinate-space neighbours).  bmap != NULL (B int32):
+ * the batch replicates / selects a smaller one -- element bb of the tensors flagged in `shared` (1 points1, 2 points2, 4 the
+ * first index list) is read from element bmap[bb] of the unreplicated tensor (Multiframe_Attention's three flow iterations share
+ * their features, mocopci.py:191-197); xyz1, xyz2 and idx2 are per element. */
 int mcp_cross_packed_floats(int d);
 int mcp_cross_pack(int d, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, float *packed,
                    mcp_stream_t stream);
 int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
-                     const float *points2, const int *idx, const int *idx2, const float *packed, float *out, mcp_stream_t stream);
+                     const float *points2, const int *idx, const int *idx2, const int *bmap, int shared, const float *packed, float *out, mcp_stream_t stream);
 
 /* PointConv / PointConvD up to the final Linear (mocopci.py:1218-1266, :1289-1300, :1330-1335):
  * s_xyz (B,N,3), new_xyz (B,S,3) centres, s_points (B,N,D) channel-last, idx (B,S,32) int32 into the

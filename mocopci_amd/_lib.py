@@ -47,7 +47,7 @@ SIGNATURES = {
     "mcp_fusion": [_i, _i, _i] + [_p] * 12,
     "mcp_cross_packed_floats": [_i],
     "mcp_cross_pack": [_i, _p, _p, _p, _p, _p, _p],
-    "mcp_cross_volume": [_i] * 5 + [_p] * 9,
+    "mcp_cross_volume": [_i] * 5 + [_p] * 7 + [_i, _p, _p, _p],
     "mcp_pointconv_agg": [_i] * 5 + [_p] * 12,
     "mcp_attention_small": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
     "mcp_attention_wide": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],

@@ -139,8 +139,8 @@ template <int D, int SPLIT>
 __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) void cross_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
                                                            const float *__restrict__ xyz2, const float *__restrict__ points1,
                                                            const float *__restrict__ points2, const int *__restrict__ idx,
-                                                           const int *__restrict__ idx2, const float *__restrict__ packed,
-                                                           float *__restrict__ out) {
+                                                           const int *__restrict__ idx2, const int *__restrict__ bmap, int shared,
+                                                           const float *__restrict__ packed, float *__restrict__ out) {
     using L = CrossLds<D>;
     constexpr int T = L::T, KQ = T * 4;  // k-quads per output tile (f32 image)
     constexpr int WAVES = CrossShape<D>::NW;
@@ -168,14 +168,23 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
     // gathered points2 row and (D = 64 only: at D = 128 it would spill) points1 row, both in accumulator layout
     constexpr bool PRE_A = D <= 64;
     float4 ra[PRE_A ? T : 1][4], rg[T][4];
+    // bmap != NULL: the batch is a replication / selection of a smaller one (the three flow iterations of multiframe_attention see
+    // the same features): batch element bb of the tensors flagged in `shared` (1: points1, 2: points2, 4: the first index list)
+    // is read from element bmap[bb] of the unreplicated tensor -- nothing is copied.  xyz1 / xyz2 and the second list are per element.
+    auto src1 = [&](long long pp) {  // row of points1 for point pp
+        if (!(bmap && (shared & 1))) return pp;
+        const long long bb = pp / n1;
+        return (long long)bmap[bb] * n1 + (pp - bb * n1);
+    };
     auto fetch = [&](long long pp, int id) {
         const long long bb = pp / n1;
         const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
         const float dx = q2[0] - xyz1[pp * 3 + 0], dy = q2[1] - xyz1[pp * 3 + 1], dz = q2[2] - xyz1[pp * 3 + 2];
         in0 = h ? dy : dx;
         in1 = h ? 1.0f : dz;
-        const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)bb * n2 + id) * D);
-        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + pp * D);
+        const long long b2 = (bmap && (shared & 2)) ? bmap[bb] : bb;
+        const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)b2 * n2 + id) * D);
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + src1(pp) * D);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -185,7 +194,16 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
             }
     };
     // idx2 != NULL: the 16 feature-space and the 16 coordinate-space neighbours come as two (B,N1,16) lists
-    auto nbr = [&](long long pp) { return idx2 ? (col < 16 ? idx[pp * 16 + col] : idx2[pp * 16 + col - 16]) : idx[pp * KNB + col]; };
+    auto nbr = [&](long long pp) {
+        if (!idx2) return idx[pp * KNB + col];
+        if (col >= 16) return idx2[pp * 16 + col - 16];
+        long long ps = pp;
+        if (bmap && (shared & 4)) {
+            const long long bb = pp / n1;
+            ps = (long long)bmap[bb] * n1 + (pp - bb * n1);
+        }
+        return idx[ps * 16 + col];
+    };
     long long pn = p + stride;
     int idn = 0;
     if (p < total) {
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
     for (; p < total; p = pn, pn += stride) {
         f32x16 x0[L::BF ? 1 : T];
         McpSplit3 xs[L::BF ? 2 * T : 1];
-        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + p * D);
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + src1(p) * D);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             f32x16 acc;
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
 
 template <int D, int SPLIT>
 int launch_cross(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
-                 const int *idx, const int *idx2, const float *packed, float *out, hipStream_t s) {
+                 const int *idx, const int *idx2, const int *bmap, int shared, const float *packed, float *out, hipStream_t s) {
     using L = CrossLds<D>;
     const size_t lds = (L::W_FLOATS / SPLIT + L::POS_FLOATS + L::B_FLOATS) * sizeof(float);
     auto kern = cross_kernel<D, SPLIT>;
@@ -266,7 +284,7 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
     // persistent-style grid = exactly the resident slots (256 CUs x 3 or 2 workgroups, see __launch_bounds__): a larger
     // grid leaves a partly filled second round of workgroups
     const unsigned grid = (unsigned)max(1LL, min(want, (long long)(CrossShape<D>::GRID / SPLIT)));
-    hipLaunchKernelGGL(kern, dim3(grid, SPLIT), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, packed, out);
+    hipLaunchKernelGGL(kern, dim3(grid, SPLIT), dim3(64 * WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared, packed, out);
     return mcp_launch_status();
 }
 
@@ -289,16 +307,17 @@ MCP_EXPORT int mcp_cross_pack(int d, const float *wpos, const float *bpos, const
 }
 
 MCP_EXPORT int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
-                                const float *points2, const int *idx, const int *idx2, const float *packed, float *out, mcp_stream_t stream) {
+                                const float *points2, const int *idx, const int *idx2, const int *bmap, int shared, const float *packed, float *out,
+                                mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && packed && out);
     if (k != KNB || (d != 64 && d != 128 && d != 256)) return MCP_ERR_UNSUPPORTED;
     if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)out) | ((uintptr_t)packed)) & 15) return MCP_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)b * n1;
     mcp_prof_begin(MCP_KERNEL_CROSS, s);
-    const int rc = d == 64    ? launch_cross<64, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, packed, out, s)
-                   : d == 128 ? launch_cross<128, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, packed, out, s)
-                              : launch_cross<256, 2>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, packed, out, s);
+    const int rc = d == 64    ? launch_cross<64, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared, packed, out, s)
+                   : d == 128 ? launch_cross<128, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared, packed, out, s)
+                              : launch_cross<256, 2>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared, packed, out, s);
     mcp_prof_end(MCP_KERNEL_CROSS, s);
     return rc;
 }

@@ -299,7 +299,7 @@ class MoCoPCI(nn.Module):
         f4 = self.pointconv(p + "level4", pc3, pc4, f3_4)
         return [xyz, pc1, pc2, pc3, pc4], [f0, f1, f2, f3, f4]
 
-    def cross(self, xyz1, xyz2, points1, points2, knn1, knn2, pos, mlp, sorted_p3d, idx_c=None):
+    def cross(self, xyz1, xyz2, points1, points2, knn1, knn2, pos, mlp, sorted_p3d, idx_c=None, bmap=None, shared=0):
         """cost-volume cross() (pointconv_util.py:750-781; :894-922 with pytorch3d knn_points;
         :1126-1161).  16 feature-cosine neighbours then 16 xyz neighbours of set 2 per point of
         set 1, LeakyReLU(g2 + p1 + pos(dxyz)), 1x1 convs, max over the 32 neighbours."""
@@ -315,11 +315,12 @@ class MoCoPCI(nn.Module):
         idx = (idx_c.contiguous(), idx_p)                                 # the two 16-neighbour lists, read in place by the kernel
         # every cross() MoCoPCI builds has one D -> D mlp layer with D in {64, 128, 256} (pointconv_util.py:735-748)
         assert len(mlp) == 1 and points2.shape[-1] == points1.shape[-1]
+        # bmap / shared: points1, points2 and idx_c hold the UNREPLICATED batch of multiframe_attention's three iterations
         conv = mlp[0] + ".composed_module.0"
         w = (self.W(pos), self.Bv(pos), self.W(conv), self.Bv(conv))
         # the layer's weights in the kernel's operand layout, built once (inference); a training forward packs the live weights
         packed = None if self._live is not None else self.derived(("cross_pack", be.name, pos, conv), lambda: be.cross_pack(*w))
-        return be.cross_layer(xyz1, xyz2, points1, points2, idx, *w, packed=packed)
+        return be.cross_layer(xyz1, xyz2, points1, points2, idx, *w, packed=packed, bmap=bmap, shared=shared)
 
     def interp(self, dense, sparse, feat, cache=None, key=None):
         """UpsampleFlow (mocopci.py:1485-1502) with search reuse on a keyed (dense, sparse) pair."""
@@ -333,10 +334,11 @@ class MoCoPCI(nn.Module):
 
     def interp_flows(self, dense, sparse, flows, cache, key):
         """The three per-frame flow upsamples (mocopci.py:870-878, :936-944) as ONE interpolation: flows (B,3,S,3) are
-        laid side by side as 9 channels (same 3-NN and weights for all of them)."""
+        laid side by side as 9 channels (same 3-NN and weights for all of them).  Returns them stacked frame-major,
+        (3*B,N,3) -- the arrangement multiframe_attention batches its three iterations in."""
         B, R, S, _ = flows.shape
         up = self.interp(dense, sparse, flows.permute(0, 2, 1, 3).reshape(B, S, R * 3), cache, key)      # (B,N,9)
-        return [up[..., 3 * i:3 * i + 3].contiguous() for i in range(R)]
+        return up.reshape(B, -1, R, 3).permute(2, 0, 1, 3).reshape(R * B, -1, 3)
 
     def warp(self, xyz1, xyz2, flow1):
         """PointWarping.forward (mocopci.py:1458-1482)."""
@@ -457,6 +459,14 @@ class MoCoPCI(nn.Module):
             self._time_cache[key] = torch.tensor(values, device=device)
         return self._time_cache[key]
 
+    def batch_map(self, values, device):
+        """int32 device tensor of a static batch map (see ops.cross_volume), built once."""
+        key = ("bmap", values, str(device))
+        self.__dict__.setdefault("_time_cache", {})
+        if key not in self._time_cache:
+            self._time_cache[key] = torch.tensor(values, dtype=torch.int32, device=device)
+        return self._time_cache[key]
+
     def area_matrix(self, n_in, n_out, device):
         """F.interpolate(mode="area") = adaptive average pooling along the last axis, as an (n_in, n_out) matrix: output j
         averages inputs floor(j*n_in/n_out) .. ceil((j+1)*n_in/n_out)-1.  (3 -> 32: one or two inputs per output, so the
@@ -514,8 +524,8 @@ class MoCoPCI(nn.Module):
         # The loop over the 3 upsampled flows (mocopci.py:191-197) has no carried dependency -- the bid/fe layers always
         # see the original c_feat1/c_feat2 -- so the three iterations run as one batch of 3 x (2B); feat1_new/feat2_new
         # after the loop are those of the last iteration.
-        R = len(up_frames)
         B2 = pc1.shape[0]
+        R = up_frames.shape[0] // B2                                               # up_frames: (R*B2,N,3), frame-major
         dev = pc1.device
         sel = None
         if rows is not None:
@@ -529,12 +539,22 @@ class MoCoPCI(nn.Module):
         rep = expand if sel is None else (lambda t: expand(t)[sel])
         pick = (lambda t: t) if sel is None else (lambda t: t[sel])
         pc1r, pc2r = rep(pc1), rep(pc2)
-        ic12, ic21 = rep(idx_c12), rep(idx_c21)
-        pc2w = self.warp(pc1r, pc2r, pick(torch.cat(list(up_frames), dim=0)))
-        n1a = self.cross(pc1r, pc2w, rep(t11_1), rep(t22_2), None, None, b + ".pos", bid_mlp, True, ic12)
-        n2a = self.cross(pc2w, pc1r, rep(t11_2), rep(t22_1), None, None, b + ".pos", bid_mlp, True, ic21)
-        fea = self.cross(pc1r, pc2w, self.lin(n1a, fe + ".conv1"), self.lin(n2a, fe + ".conv2"), None, None, fe + ".pos", fe_mlp,
-                         False, ic12)
+        pc2w = self.warp(pc1r, pc2r, pick(up_frames))
+        if self._live is None:
+            # inference: the features and the feature-space neighbour lists of the R iterations are the same tensors; the
+            # kernel reads batch element b of them from element b mod 2B through a batch map instead of R copies
+            members = need if sel is not None else list(range(R * B2))
+            bmap = self.batch_map(tuple(i % B2 for i in members), dev)
+            n1a = self.cross(pc1r, pc2w, t11_1, t22_2, None, None, b + ".pos", bid_mlp, True, idx_c12, bmap=bmap, shared=7)
+            n2a = self.cross(pc2w, pc1r, t11_2, t22_1, None, None, b + ".pos", bid_mlp, True, idx_c21, bmap=bmap, shared=7)
+            fea = self.cross(pc1r, pc2w, self.lin(n1a, fe + ".conv1"), self.lin(n2a, fe + ".conv2"), None, None, fe + ".pos", fe_mlp,
+                             False, idx_c12, bmap=bmap, shared=4)
+        else:
+            ic12, ic21 = rep(idx_c12), rep(idx_c21)
+            n1a = self.cross(pc1r, pc2w, rep(t11_1), rep(t22_2), None, None, b + ".pos", bid_mlp, True, ic12)
+            n2a = self.cross(pc2w, pc1r, rep(t11_2), rep(t22_1), None, None, b + ".pos", bid_mlp, True, ic21)
+            fea = self.cross(pc1r, pc2w, self.lin(n1a, fe + ".conv1"), self.lin(n2a, fe + ".conv2"), None, None, fe + ".pos", fe_mlp,
+                             False, ic12)
         if sel is not None:  # back to the 3 x (2B) layout; the dropped members are never read
             full = fea.new_zeros((R * B2, *fea.shape[1:]))
             full[sel] = fea

@@ -288,24 +288,32 @@ class HipBackend:
               _lib.fptr(bmlp.contiguous()), _lib.fptr(packed))
         return packed
 
-    def cross_volume(self, xyz1, xyz2, points1, points2, idx, packed):
+    def cross_volume(self, xyz1, xyz2, points1, points2, idx, packed, bmap=None, shared=0):
         """cross() after its neighbour searches (pointconv_util.py:750-781): -> (B,N1,D); D in {64,128,256};
-        packed = cross_pack(wpos, bpos, wmlp, bmlp)."""
-        B, N1, D = points1.shape
-        N2 = points2.shape[1]
+        packed = cross_pack(wpos, bpos, wmlp, bmlp).  bmap (B int32) + shared (1 points1, 2 points2, 4 first index list): those
+        tensors hold a smaller batch and element b is read from their element bmap[b] (replicated inputs are not copied)."""
+        B, N1 = xyz1.shape[0], xyz1.shape[1]
+        D = points1.shape[2]
+        N2 = xyz2.shape[1]
         out = torch.empty((B, N1, D), dtype=torch.float32, device=points1.device)
         ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)   # the 16 + 16 halves as the searches produce them, or one list
         k = ia.shape[-1] if ib is None else ia.shape[-1] + ib.shape[-1]
+        if bmap is not None and (shared & 4) and ib is None:
+            raise RuntimeError("a shared index list needs the two-list form")
         _call("mcp_cross_volume", points1, B, N1, N2, D, k, _lib.fptr(xyz1), _lib.fptr(xyz2), _lib.fptr(points1),
-              _lib.fptr(points2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib), _lib.fptr(packed), _lib.fptr(out))
+              _lib.fptr(points2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib), None if bmap is None else _lib.iptr(bmap), int(shared),
+              _lib.fptr(packed), _lib.fptr(out))
         return out
 
-    def cross_layer(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, packed=None):
+    def cross_layer(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, packed=None, bmap=None, shared=0):
         """cross() from the layer's own weights; differentiable w.r.t. coordinates, features and weights.  packed: the
-        cross_pack image of these weights when the caller keeps one (inference); built on the fly otherwise."""
+        cross_pack image of these weights when the caller keeps one (inference); built on the fly otherwise.  bmap / shared:
+        see cross_volume (inference only: a training forward passes the replicated tensors)."""
         def fused(x1, x2, f1, f2, i, wp, bp, wm, bm):
             pk = packed if packed is not None else self.cross_pack(wp, bp, wm, bm)
-            return self.cross_volume(x1.contiguous(), x2.contiguous(), f1.contiguous(), f2.contiguous(), i, pk)
+            return self.cross_volume(x1.contiguous(), x2.contiguous(), f1.contiguous(), f2.contiguous(), i, pk, bmap=bmap, shared=shared)
+        if bmap is not None:
+            return fused(xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp)
         return grad.run(fused, lambda *a: grad.cross_twin(self.group_rows, *a), xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp)
 
     def ptblock_layer(self, xyz, q, k, v, idx, weights, packed=None):

@@ -88,7 +88,12 @@ class OracleBackend:
     def ptblock_pack(self, *weights):
         return weights
 
-    def cross_layer(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, packed=None):
+    def cross_layer(self, xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp, packed=None, bmap=None, shared=0):
+        if bmap is not None:  # replicated / selected batch: element b of the flagged tensors comes from their element bmap[b]
+            m = bmap.long()
+            points1 = points1[m] if shared & 1 else points1
+            points2 = points2[m] if shared & 2 else points2
+            idx = (idx[0][m], idx[1]) if shared & 4 else idx
         return self.cross_volume(xyz1, xyz2, points1, points2, idx, (wpos, bpos, wmlp, bmlp))
 
     def ptblock_layer(self, xyz, q, k, v, idx, weights, packed=None):

@@ -586,3 +586,27 @@ def test_linear_matches_unfused_oracle(rows, ks, n, slope, with_res):
     torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
     # shapes outside the policy are declined (the caller then takes the BLAS chain)
     assert not be.linear_supported(xd[0][:2048], n) and not be.linear_supported(torch.empty(20000, 600, device=DEV), 64)
+
+
+def test_cross_volume_batch_map_equals_replicated_inputs():
+    """Replicated / selected batches (the three flow iterations of Multiframe_Attention share their features, mocopci.py:191-197)
+    are read through a batch map instead of being copied: same bits as the call on the materialised copies."""
+    g = torch.Generator().manual_seed(77)
+    B0, n, d = 4, 300, 64
+    members = [0, 1, 2, 3, 0, 2, 3, 1, 1]                       # a 9-element batch drawn from 4 sources
+    p1, p2 = torch.randn(B0, n, d, generator=g), torch.randn(B0, n, d, generator=g)
+    idx_c = torch.randint(0, n, (B0, n, 16), generator=g, dtype=torch.int32)
+    xyz1, xyz2 = cloud(83, len(members), n), cloud(84, len(members), n)
+    idx_p = torch.randint(0, n, (len(members), n, 16), generator=g, dtype=torch.int32)
+    w = [torch.randn(d, 3, generator=g) * 0.3, torch.randn(d, generator=g) * 0.1, torch.randn(d, d, generator=g) / d ** 0.5, torch.randn(d, generator=g) * 0.1]
+    be = ops.backend()
+    packed = be.cross_pack(*[t.to(DEV) for t in w])
+    m = torch.tensor(members)
+    want = be.cross_volume(xyz1.to(DEV), xyz2.to(DEV), p1[m].contiguous().to(DEV), p2[m].contiguous().to(DEV),
+                           (idx_c[m].contiguous().to(DEV), idx_p.to(DEV)), packed)
+    got = be.cross_volume(xyz1.to(DEV), xyz2.to(DEV), p1.to(DEV), p2.to(DEV), (idx_c.to(DEV), idx_p.to(DEV)), packed,
+                          bmap=m.int().to(DEV), shared=7)
+    assert torch.equal(got, want)
+    got4 = be.cross_volume(xyz1.to(DEV), xyz2.to(DEV), p1[m].contiguous().to(DEV), p2[m].contiguous().to(DEV), (idx_c.to(DEV), idx_p.to(DEV)),
+                           packed, bmap=m.int().to(DEV), shared=4)
+    assert torch.equal(got4, want)
