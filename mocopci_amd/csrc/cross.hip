@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
         const long long bb = pp / n1;
         return (long long)bmap[bb] * n1 + (pp - bb * n1);
     };
+    long long r1next = 0;
     auto fetch = [&](long long pp, int id) {
         const long long bb = pp / n1;
         const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
         in1 = h ? 1.0f : dz;
         const long long b2 = (bmap && (shared & 2)) ? bmap[bb] : bb;
         const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)b2 * n2 + id) * D);
-        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + src1(pp) * D);
+        r1next = src1(pp);  // kept for the accumulator initialisation of that point (no second map lookup on its critical path)
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + r1next * D);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
     for (; p < total; p = pn, pn += stride) {
         f32x16 x0[L::BF ? 1 : T];
         McpSplit3 xs[L::BF ? 2 * T : 1];
-        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + src1(p) * D);
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + r1next * D);  // set by the fetch of this point
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             f32x16 acc;
