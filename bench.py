@@ -35,6 +35,10 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s 
 MFMA_F32_PEAK_TFLOPS = 157.3    # f32-input MFMA (v_mfma_f32_32x32x2_f32): 64 FLOP/clk/SIMD
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 SPLIT_PRODUCTS = 6              # bf16 partial products per fp32 product on the split path (mocopci_amd/csrc/mfma_split.h)
+# What a pure v_mfma_f32_32x32x16_bf16 stream sustains on this chip once the operand bits toggle (tools/mfma_peak.py --random,
+# profiles/r02_mfma_sustained.txt: power management holds the clock near 1.8 GHz; 0.99 of the datasheet figure with all-ones operands).
+# Reported beside `peak`, never instead of it.
+MFMA_BF16_SUSTAINED_TFLOPS = 1865.0
 NPOINTS = 8192
 B_PER_GPU = 8
 FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock", "mlp", "linear")
@@ -156,6 +160,10 @@ def roofline_entries(timed, calls, steps, pmc):
         e = {"kernel": NAMES[kname], "bound": bound, "achieved": ach, "peak": peak, "unit": u, "frac": ach / peak,
              "traffic": None, "launches": launches, "launches_per_step": launches // steps, "avg_launch_us": 1e6 * avg_s,
              "kernel_ms_per_step": kms / steps, "note": NOTES[kname]}
+        if unit != "bytes" and kname in ("fusion", "cross", "ptblock", "mlp"):
+            e["sustained_peak"] = MFMA_BF16_SUSTAINED_TFLOPS / SPLIT_PRODUCTS
+            e["frac_of_sustained_peak"] = ach / e["sustained_peak"]
+            e["sustained_peak_source"] = "profiles/r02_mfma_sustained.txt (measured bf16 MFMA stream with random operand bits: 0.75 of the datasheet peak)"
         p = pmc.get(kname, {})
         if "hbm_bytes_per_launch" in p:
             e["traffic"] = p["hbm_bytes_per_launch"]

@@ -37,6 +37,11 @@ __device__ __forceinline__ McpSplit3 mcp_split8(const float *v) {
         r2[i] = r1[i] - __uint_as_float(mcp_top16(r1[i]));    // exact; at most 8 significant bits remain
     }
     McpSplit3 o;
+#ifdef MCP_SPLIT_DIAG_NOSPLIT  // timing-only diagnostic build (wrong results): no residual arithmetic, one packing pass
+    o.p1 = make_uint4(mcp_pack_hi(v[0], v[1]), mcp_pack_hi(v[2], v[3]), mcp_pack_hi(v[4], v[5]), mcp_pack_hi(v[6], v[7]));
+    o.p2 = o.p1; o.p3 = o.p1;
+    return o;
+#endif
     o.p1 = make_uint4(mcp_pack_hi(v[0], v[1]), mcp_pack_hi(v[2], v[3]), mcp_pack_hi(v[4], v[5]), mcp_pack_hi(v[6], v[7]));
     o.p2 = make_uint4(mcp_pack_hi(r1[0], r1[1]), mcp_pack_hi(r1[2], r1[3]), mcp_pack_hi(r1[4], r1[5]), mcp_pack_hi(r1[6], r1[7]));
     o.p3 = make_uint4(mcp_pack_hi(r2[0], r2[1]), mcp_pack_hi(r2[2], r2[3]), mcp_pack_hi(r2[4], r2[5]), mcp_pack_hi(r2[6], r2[7]));
@@ -72,10 +77,12 @@ __device__ __forceinline__ mcp_f32x16 mcp_tile_split(const uint4 *ws, const McpS
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
         uint4 n1 = w1, n2 = w2, n3 = w3;
+#ifndef MCP_SPLIT_DIAG_NOLOAD  // timing-only diagnostic build (wrong results): every k-step reuses step 0's weights
         if (s + 1 < KSTEPS) {
             const uint4 *nx = ws + (size_t)(s + 1) * 3 * 64;
             n1 = nx[0]; n2 = nx[64]; n3 = nx[128];
         }
+#endif
         acc = mcp_mfma_bf16(w3, xs[s].p1, acc);
         acc = mcp_mfma_bf16(w1, xs[s].p3, acc);
         acc = mcp_mfma_bf16(w2, xs[s].p2, acc);
