@@ -28,7 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import grad, ops
 
 _SPEC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "state_dict_spec.json")
 LEAKY = 0.1  # mocopci.py:1107, pointconv_util.py:10
@@ -82,6 +82,12 @@ class Early:
 class MoCoPCI(nn.Module):
     T_F = [0.0, 0.41666666666666663, 0.5, 0.5833333333333333, 1.0]  # mocopci.py:824
     T_B = [1.0, 0.5833333333333333, 0.5, 0.41666666666666663, 0.0]  # mocopci.py:825
+    # net.train() + forward(train=True): the rates the reference constructs its blocks with (mocopci.py:165-168, :781-783);
+    # plain attributes so that a run can change them (0 switches a kind of dropout off)
+    drop_rate = 0.05        # Mlp_T / EasyMlp hidden + output dropout, attention proj_drop
+    attn_drop_rate = 0.05   # dropout on the softmax matrices of Multi_Frame_Att / Cross_Frame_Att
+    drop_path_rate = 0.04   # stochastic depth of Multi_Frame_Att's two residual branches (Cross_Frame_Att: 0)
+    BN_MOMENTUM = 0.1       # nn.BatchNorm default
 
     def __init__(self):
         super().__init__()
@@ -101,6 +107,7 @@ class MoCoPCI(nn.Module):
                 node.register_parameter(parts[-1], nn.Parameter(t))
         self._cache = None
         self._live = None  # training forward: {name: live parameter / buffer}; derived tensors are then rebuilt, not cached
+        self._mode = None  # training forward in net.train() mode: (drop, attn_drop, drop_path) -- BatchNorm then uses batch statistics
         self.eval()
 
     # ---- parameter access ---------------------------------------------------------------
@@ -112,6 +119,16 @@ class MoCoPCI(nn.Module):
         self._cache = None
         return super().load_state_dict(*a, **k)
 
+    def _state_version(self):
+        """Changes whenever a parameter or buffer is written in place (optimizer.step(), a training forward's running statistics,
+        copy_ / load) -- everything cached from them (folded BatchNorms, packed kernel operands) is then stale."""
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+
+    def _check_cache(self):
+        """Once per forward: drop the inference cache if any parameter / buffer changed since it was built."""
+        if self._cache is not None and self._cache.get(("state_version",)) != self._state_version():
+            self._cache = None
+
     def _params(self):
         if self._live is not None:
             return self._live
@@ -121,6 +138,7 @@ class MoCoPCI(nn.Module):
                 c[n] = p.detach()
             for n, b in self.named_buffers():
                 c[n] = b
+            c[("state_version",)] = self._state_version()
             self._cache = c
             self._time_cache = {}
         return self._cache
@@ -170,6 +188,56 @@ class MoCoPCI(nn.Module):
             return scale.contiguous(), (P[name + ".bias"] - P[name + ".running_mean"] * scale).contiguous()
         scale, shift = self.derived(("bn", name, eps), fold)
         return torch.addcmul(shift, x, scale)
+
+    def bn_batch(self, x, name, eps):
+        """BatchNorm in TRAINING mode applied x.shape[0] times in sequence: call g normalises x[g] (any shape, channels last) with
+        the statistics of x[g] alone and then updates the running statistics, exactly what the reference's per-sample loops
+        (`for i, x in enumerate(xs): self.norm1(x)`, mocopci.py:503-506, :554-561) and its three fusion calls do with
+        nn.BatchNorm1d / 2d: biased variance for the normalisation, unbiased for the running estimate, momentum 0.1."""
+        P = self._params()
+        G, C = x.shape[0], x.shape[-1]
+        flat = x.reshape(G, -1, C)
+        n = flat.shape[1]
+        mean = flat.mean(dim=1)
+        var = flat.var(dim=1, unbiased=False)
+        with torch.no_grad():
+            rm, rv, m = P[name + ".running_mean"], P[name + ".running_var"], self.BN_MOMENTUM
+            for g in range(G):
+                rm.mul_(1.0 - m).add_(mean[g], alpha=m)
+                rv.mul_(1.0 - m).add_(var[g], alpha=m * n / (n - 1))
+            P[name + ".num_batches_tracked"].add_(G)
+        shape = (G,) + (1,) * (x.dim() - 2) + (C,)
+        scale = P[name + ".weight"] * torch.rsqrt(var + eps)
+        return (x - mean.reshape(shape)) * scale.reshape(shape) + P[name + ".bias"]
+
+    def norm(self, x, name, eps):
+        """The block's BatchNorm on (samples, ..., C): batch statistics per sample in a net.train() training forward, the running
+        statistics otherwise."""
+        return self.bn_batch(x, name, eps) if self._mode is not None else self.bn_eval(x, name, eps)
+
+    def dropout(self, x, p):
+        return F.dropout(x, p, training=True) if self._mode is not None and p > 0.0 else x
+
+    def drop_path(self, x):
+        """timm DropPath on the leading two axes (sample, frame): the reference applies it to one sample's (frames, C, N) stack,
+        so every frame of every sample draws its own keep / drop (mocopci.py:559, :562)."""
+        p = self._mode[2] if self._mode is not None else 0.0
+        if p <= 0.0:
+            return x
+        keep = torch.empty(x.shape[:2] + (1,) * (x.dim() - 2), device=x.device, dtype=x.dtype).bernoulli_(1.0 - p)
+        return x * (keep / (1.0 - p))
+
+    def attend(self, q, kv, heads, scale=None):
+        """softmax(q k^T scale) v per head; with attention dropout (net.train()) the probabilities are materialised."""
+        p = self._mode[1] if self._mode is not None else 0.0
+        if p <= 0.0:
+            return ops.backend().attention(q, kv, heads, scale=scale)
+        BF, Nq, C = q.shape
+        Nk, hd = kv.shape[1], C // heads
+        qh = q.reshape(BF, Nq, heads, hd).permute(0, 2, 1, 3)
+        kvh = kv.reshape(BF, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+        attn = torch.softmax((qh @ kvh[0].transpose(-2, -1)) * (hd ** -0.5 if scale is None else scale), dim=-1)
+        return (F.dropout(attn, p, training=True) @ kvh[1]).permute(0, 2, 1, 3).reshape(BF, Nq, C)
 
     # ---- point-set layers ---------------------------------------------------------------
     def pointconv(self, prefix, s_xyz, new_xyz, s_points, nsample=32, idx=None):
@@ -379,7 +447,8 @@ class MoCoPCI(nn.Module):
         so its 4 head slots come out as 4 'frames' (mocopci.py:619-621); the first is dropped."""
         B, Fr, N, C = x.shape
         P = self._params()
-        xn = self.bn_eval(x, prefix + ".norm1", 1e-5)
+        drop = self._mode[0] if self._mode is not None else 0.0
+        xn = self.norm(x, prefix + ".norm1", 1e-5)                                # per sample over its two frames (mocopci.py:505)
         xr = torch.flip(xn, dims=[1])
         a = prefix + ".attn_feats"
         # head slot 0 is the dropped one and nothing after the attention mixes slots: project only heads 1..3
@@ -388,22 +457,23 @@ class MoCoPCI(nn.Module):
             sl = lambda t: None if t is None else torch.cat([t[C:4 * C], t[5 * C:8 * C]], dim=0).contiguous()
             return wq[C:].contiguous(), None if bq is None else bq[C:].contiguous(), sl(wkv), sl(bkv)
         wq, bq, wkv, bkv = self.derived(("cfa_heads", prefix), heads)
-        o = ops.backend().attention(F.linear(xn, wq, bq).reshape(B * Fr, N, 3 * C), F.linear(xr, wkv, bkv).reshape(B * Fr, N, 6 * C), 3,
-                                    scale=C ** -0.5)                              # (B*2,N,3C): 3 head slots, each C wide
-        o = self.lin(o.reshape(B, Fr, N, 3, C).sum(dim=1).transpose(1, 2), a + ".proj")   # (B,3,N,C)
+        o = self.attend(F.linear(xn, wq, bq).reshape(B * Fr, N, 3 * C), F.linear(xr, wkv, bkv).reshape(B * Fr, N, 6 * C), 3,
+                        scale=C ** -0.5)                                          # (B*2,N,3C): 3 head slots, each C wide
+        o = self.dropout(self.lin(o.reshape(B, Fr, N, 3, C).sum(dim=1).transpose(1, 2), a + ".proj"), drop)   # (B,3,N,C)
         t = prefix + ".trans_block_2"
-        if not feats:  # only the flows are read (MultiFrameEstimatier.forward never uses cross_block3's features in inference)
+        if not feats and drop <= 0.0:  # only the flows are read (MultiFrameEstimatier.forward never uses cross_block3's features)
             return None, self.mlp_t(t, o, tail=prefix + ".mapping_xyz")
-        xa = self.mlp_t(t, o)
+        xa = self.mlp_t(t, o, drop=drop)
         frames = self.lin(xa, prefix + ".mapping_xyz")
         return xa, frames                                                         # (B,3,N,C), (B,3,N,3)
 
-    def mlp_t(self, prefix, x, tail=None, res=None, bn=None):
+    def mlp_t(self, prefix, x, tail=None, res=None, bn=None, drop=0.0):
         """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2 -- as ONE fused kernel (ops.mlp2).  Everything
         affine around the first layer is folded into it once: the depthwise k=1 conv is a per-channel scale + bias,
         (W x + b) * s + t = (s W) x + (s b + t); bn = (name, eps) is an eval-mode BatchNorm applied to x first,
         W (g x + h) + b = (W diag g) x + (W h + b).  tail: a Linear applied to the result (mapping_xyz), folded into fc2 where
-        only the 3-channel flow is read.  res: residual added to the result (inside the kernel)."""
+        only the 3-channel flow is read.  res: residual added to the result (inside the kernel).  drop > 0 (net.train()): the
+        reference's dropout after the activation and after fc2 (mocopci.py:1561-1564, :1592-1595) -- the layers then run unfused."""
         P = self._params()
         be = ops.backend()
 
@@ -420,8 +490,9 @@ class MoCoPCI(nn.Module):
             return w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
         w1, b1, w2, b2 = self.derived(("mlp_t", prefix, tail, bn), fold)
         live = self._live is not None
-        if not be.mlp2_supported(w1.shape[1], w1.shape[0], w2.shape[0]):  # widths the kernel is not built for (feature outputs)
-            out = F.linear(F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"]), w2, b2)
+        if drop > 0.0 or not be.mlp2_supported(w1.shape[1], w1.shape[0], w2.shape[0]):  # dropout, or widths the kernel is not built for
+            hid = self.dropout(F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"]), drop)
+            out = self.dropout(F.linear(hid, w2, b2), drop)
             return out if res is None else out + res
         # the PReLU slope: the live parameter in a training forward (it gets its gradient), a cached float otherwise
         slope = P[prefix + ".act.weight"] if live else self.derived(("slope", prefix), lambda: float(P[prefix + ".act.weight"]))
@@ -450,6 +521,24 @@ class MoCoPCI(nn.Module):
         xf = self.mlp_t(prefix + ".trans_block", x)                               # (B,3,N,latent)
         frames = self.lin(xf, prefix + ".mapping_xyz")                            # (B,3,N,3)
         return xf, frames
+
+    def multi_frame_att_full(self, prefix, x, heads=8):
+        """Multi_Frame_Att.forward (mocopci.py:551-575) on all five frames, for a net.train() training forward: BatchNorm with
+        each sample's own statistics over its five frames (so the outer two cannot be skipped), attention / projection /
+        MLP dropout and stochastic depth.  x (B,5,N,C) -> (feature frames, flow frames) of the inner three."""
+        B, Fr, N, C = x.shape
+        drop = self._mode[0]
+        xn = self.bn_batch(x, prefix + ".norm1", 1e-5)
+        xr = torch.flip(xn, dims=[1])
+        a = prefix + ".attn_feats"
+        o = self.attend(self.lin(xn, a + ".q").reshape(B * Fr, N, C), self.lin(xr, a + ".kv").reshape(B * Fr, N, 2 * C), heads)
+        o = self.dropout(self.lin(o.reshape(B, Fr, N, C), a + ".proj"), drop)
+        xn = xn + self.drop_path(o)                                               # mocopci.py:559
+        xb = self.bn_batch(xn, prefix + ".norm2", 1e-5)
+        x = x + self.drop_path(self.mlp_t(prefix + ".mlp", xb, drop=drop))        # mocopci.py:561-563
+        xf = self.mlp_t(prefix + ".trans_block", x, drop=drop)
+        frames = self.lin(xf, prefix + ".mapping_xyz")
+        return xf[:, 1:-1], frames[:, 1:-1]
 
     def index_tensor(self, values, device):
         """int64 device tensor of a small static index list, built once (no host-to-device copy inside the forward)."""
@@ -563,6 +652,9 @@ class MoCoPCI(nn.Module):
         n1, n2 = n1a[-B2:], n2a[-B2:]  # last iteration's (unused when rows are selected)
         # mocopci.py:203 stacks [feat1_new, fe_0..2, feat2_new] + time codes as 5 frames; Multi_Frame_Att keeps only the
         # inner three (see multi_frame_att), so the two outer frames are never built here
+        if self._mode is not None:  # net.train(): the block's BatchNorms see all five frames of a sample (mocopci.py:200-208)
+            _, frames = self.multi_frame_att_full(prefix + ".cross_block", torch.stack([n1, *fes, n2], dim=1) + time_enc)
+            return frames, n1, n2
         x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                            # (B,3,N,C)
         # (the block's third output, downsample(x_f), is never read by MultiFrameEstimatier.forward in inference)
         if rows is not None:  # only some (sample, frame) flows are read downstream
@@ -603,15 +695,32 @@ class MoCoPCI(nn.Module):
             return (self.W(conv) * scale[:, None]).contiguous(), ((self.Bv(conv) - P[bn + ".running_mean"]) * scale + P[bn + ".bias"]).contiguous()
         return self.derived(("fold", conv, bn), fold)
 
-    def fusion(self, p1, p2, k=32, idx_self=None):
+    def fusion(self, p1, p2, k=32, idx_self=None, calls=1):
         """MultiFrameEstimatier.knn_group + fusion (mocopci.py:798-819).  p1, p2 (B,N,3)."""
         be = ops.backend()
         m = "multi_frame_inference.conv."
         if idx_self is None:
             idx_self = be.knn(p1, p1, k)
         idx = (idx_self, be.knn(p1, p2, k))                                        # 2 x (B,N,k), both index p2
+        if self._mode is not None:
+            return self.fusion_batch_stats(p1, p2.contiguous(), idx, calls)
         wb = [t for ci, bi in ((0, 1), (3, 4), (6, 7)) for t in self.folded_conv_bn(m + str(ci), m + str(bi), 1e-3)]
         return be.fusion_mlp(p1, p2.contiguous(), idx, *wb)
+
+    def fusion_batch_stats(self, p1, p2, idx, calls):
+        """fusion (mocopci.py:810-819) in a net.train() forward: the three Conv2d + BatchNorm2d(eps 1e-3) + ReLU layers with BATCH
+        statistics, so nothing can be folded and the layers run unfused on the gathered (B,N,64,.) tensor.  The batch holds
+        `calls` consecutive reference calls (the three interpolated frames, mocopci.py:1046-1051), each normalised with its own
+        statistics, running estimates updated call by call."""
+        m = "multi_frame_inference.conv."
+        nb = ops.backend().group_rows(p2, grad.whole(idx))                         # (B,N,64,3)
+        resi = nb - p1.unsqueeze(2)
+        x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)
+        for ci, bi in ((0, 1), (3, 4), (6, 7)):
+            x = F.linear(x, self.W(m + str(ci)), self.Bv(m + str(ci)))
+            x = torch.relu(self.bn_batch(x.reshape(calls, -1, x.shape[-1]), m + str(bi), 1e-3).reshape(x.shape))
+        wgt = torch.softmax(x.max(dim=-1)[0], dim=-1)
+        return torch.sum(wgt.unsqueeze(-1) * nb, dim=2)
 
     # ---- decoder ------------------------------------------------------------------------
     def run_decoder(self, pcs, feats, B, train=False):
@@ -730,7 +839,7 @@ class MoCoPCI(nn.Module):
             shape = self.transformer_block(m + "shape1", dfeat, down)
             upf = ops.backend().interp3(warped, down, shape)
         refine = self.lin(self.lin(upf, m + "pred.0", slope=0.0), m + "pred.2")    # (3B,N,3): Linear, ReLU, Linear
-        final = self.fusion(warped, refine, idx_self=idx_self)
+        final = self.fusion(warped, refine, idx_self=idx_self, calls=3)
         out_lst = [final[:B], final[B:2 * B], final[2 * B:]]
         if not train:
             return out_lst
@@ -748,15 +857,20 @@ class MoCoPCI(nn.Module):
         """MoCoPCI.forward (mocopci.py:1069-1097): xyz1, xyz2 (B,3,N) -> out_lst, 3 x (B,N,3).
         train=True: (frames_lst_f, frames_lst_b, gt_frame, out_lst) as the reference returns, computed with autograd enabled so
         that train.py:135-160's loss can be back-propagated: gradients reach every parameter through the fused kernels
-        (mocopci_amd.grad).  gt: 3 x (B,3,N) as train.py:125-126 passes it.  Normalisation layers use their running statistics
-        and dropout / stochastic depth are not applied in either mode (the reference's nn.Dropout(0.05) / DropPath(0.04) draw from
-        the device RNG and cannot be pinned; a fine-tuning run from a checkpoint behaves like the reference's net.eval() graph).
+        (mocopci_amd.grad).  gt: 3 x (B,3,N) as train.py:125-126 passes it.  As in the reference, what the normalisation and
+        dropout layers do then follows the MODULE's mode: after net.train() (train.py:130) the BatchNorms of the fusion MLP,
+        Multi_Frame_Att and Cross_Frame_Att normalise with batch statistics -- per sample where the reference loops over
+        samples -- and update their running estimates, and dropout / stochastic depth are drawn at drop_rate / attn_drop_rate /
+        drop_path_rate (torch's device RNG; the fused MLP / attention kernels give way to their unfused forms where a mask sits
+        between their stages); after net.eval() (the constructor's state) the same call differentiates the inference graph
+        (running statistics, no dropout).  A forward with train=False is always the inference graph.
         inputs_ready (inference, optional): a torch.cuda.Event after which xyz1 / xyz2 are complete (e.g. recorded by the loader's
         copy stream).  The furthest-point-sampling pyramid of the encoder depends on nothing but the inputs and is a 1.5 ms chain
         of latency-bound kernels on 16 CUs; with the event it is issued on the side stream behind THAT event instead of behind
         the caller's whole stream, so in a loop of forwards it runs under the tail of the previous call (pipelining of
         consecutive batches; a single isolated call is unchanged).  Without it the stream-ordered default applies."""
         B = xyz1.shape[0]
+        self._check_cache()
         if not train:
             with torch.no_grad(), ops.backend().cloud_scope():
                 pyramid = None
@@ -778,6 +892,7 @@ class MoCoPCI(nn.Module):
                 return self.run_decoder(pcs, feats, B)
         xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
         self._live = {**dict(self.named_parameters()), **dict(self.named_buffers())}
+        self._mode = (float(self.drop_rate), float(self.attn_drop_rate), float(self.drop_path_rate)) if self.training else None
         try:
             with torch.enable_grad(), ops.backend().cloud_scope():
                 self._early = Early(self, xyz.device)
@@ -785,6 +900,7 @@ class MoCoPCI(nn.Module):
                 flows_f, flows_b, out_lst = self.run_decoder(pcs, feats, B, train=True)
         finally:
             self._live = None
+            self._mode = None
         N = xyz1.shape[2]
         gt_frame = []
         if gt is not None:

@@ -146,14 +146,23 @@ def test_chamfer_gradients():
     compare_grads(lambda a, b: be.chamfer(a, b), lambda a, b: ob.chamfer(a, b), [x, y], names=["x", "y"])
 
 
-def test_one_training_step_matches_the_oracle_backend():
-    """MoCoPCI.forward(train=True) (mocopci.py:1076-1097) + the multi-scale Chamfer objective of train.py:135-160, N=1024, one
+@pytest.mark.parametrize("module_mode", ["eval", "train"])
+def test_one_training_step_matches_the_oracle_backend(module_mode):
+    """module_mode "train": after net.train() (batch-statistics BatchNorm, dropout rates set to 0 so both runs are deterministic);
+    "eval": the inference graph differentiated.
+    MoCoPCI.forward(train=True) (mocopci.py:1076-1097) + the multi-scale Chamfer objective of train.py:135-160, N=1024, one
     sequence: loss within 1e-4 relative of the CPU oracle-backend run of the same graph, parameter gradients aligned (cosine
     >= 0.999 and norms within 1 %: single near-tie neighbour flips move individual gradient entries), every parameter the
     reference's forward uses receives a gradient, and an SGD step on the HIP side lowers the loss."""
     x1, x2, gt = synth.make_batch(1, 1, 1024)
     gtc = [g.transpose(1, 2).contiguous() for g in gt]
-    cpu_net = hc.build_model("cpu")
+    def build(device):
+        n = hc.build_model(device)
+        if module_mode == "train":
+            n.train()
+            n.drop_rate = n.attn_drop_rate = n.drop_path_rate = 0.0
+        return n
+    cpu_net = build("cpu")
     prev = ops.set_backend(OracleBackend())
     try:
         out_c = cpu_net(x1, x2, gtc, None, True)
@@ -161,7 +170,7 @@ def test_one_training_step_matches_the_oracle_backend():
         loss_c.backward()
     finally:
         ops.set_backend(prev)
-    net = hc.build_model(DEV)
+    net = build(DEV)
     to = lambda ts: [t.to(DEV) for t in ts]
     out_h = net(x1.to(DEV), x2.to(DEV), to(gtc), None, True)
     assert len(out_h[0]) == 3 and [tuple(t.shape) for t in out_h[0][0]] == [(1, 1024, 3), (1, 1024, 3), (1, 2048, 3), (1, 512, 3), (1, 256, 3)]
@@ -186,3 +195,41 @@ def test_one_training_step_matches_the_oracle_backend():
     out2 = net(x1.to(DEV), x2.to(DEV), to(gtc), None, True)
     loss2, _ = training.multiscale_loss(*out2, to(gtc))
     assert float(loss2.detach()) < float(loss_h.detach())
+
+
+def test_train_mode_batch_statistics_match_the_reference_on_the_gpu(capsys):
+    """net.train() + forward(train=True) on the HIP backend vs the reference's own net.train() forward (dropout rates 0):
+    frames, update counters and running statistics (tests/golden/train_b2_n1024.npz)."""
+    def report(msg):
+        with capsys.disabled():
+            print("\n" + msg)
+    hc.run_train_mode_check(DEV, report)
+
+
+def test_train_mode_dropout_is_drawn_from_the_torch_generator():
+    """With the reference's rates (0.05 / 0.05 / 0.04) a net.train() forward is stochastic, reproducible under the same device
+    seed, back-propagates finite gradients, and leaves net.eval() forwards untouched (no dropout there)."""
+    x1, x2, gt = synth.make_batch(1, 1, 1024, device=DEV)
+    gtc = [g.transpose(1, 2).contiguous() for g in gt]
+    net = hc.build_model(DEV)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    net.train()
+    assert (net.drop_rate, net.attn_drop_rate, net.drop_path_rate) == (0.05, 0.05, 0.04)
+
+    def run(seed):
+        net.load_state_dict(state)  # same running statistics going in
+        net.train()
+        torch.manual_seed(seed)
+        return net(x1, x2, gtc, None, True)
+    a, b, c = run(1), run(1), run(2)
+    assert all(torch.equal(u, v) for u, v in zip(a[3], b[3]))
+    assert any(not torch.equal(u, v) for u, v in zip(a[3], c[3]))
+    loss, _ = training.multiscale_loss(*c, gtc)
+    loss.backward()
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    assert len(grads) >= 280 and all(torch.isfinite(g).all() for g in grads)
+    net.load_state_dict(state)
+    net.eval()
+    with torch.no_grad():
+        e1, e2 = net(x1, x2), net(x1, x2)
+    assert all(torch.equal(u, v) for u, v in zip(e1, e2))

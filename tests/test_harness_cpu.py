@@ -74,3 +74,11 @@ def test_training_forward_and_loss_on_the_oracle_backend(oracle_backend):
     with torch.no_grad():
         for a, b in zip(net(x1, x2), out):
             assert a.shape == b.shape and not a.requires_grad
+
+
+def test_train_mode_batch_statistics_match_the_reference(oracle_backend, capsys):
+    """net.train() forward on the CPU oracle backend vs the reference's own net.train() forward (dropout rates 0)."""
+    def report(msg):
+        with capsys.disabled():
+            print("\n" + msg)
+    hc.run_train_mode_check("cpu", report)
