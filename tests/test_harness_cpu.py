@@ -82,3 +82,22 @@ def test_train_mode_batch_statistics_match_the_reference(oracle_backend, capsys)
         with capsys.disabled():
             print("\n" + msg)
     hc.run_train_mode_check("cpu", report)
+
+
+def test_inference_cache_follows_in_place_parameter_updates(oracle_backend):
+    """Folded BatchNorms / packed operands are cached for inference; an in-place update of a parameter or buffer (optimizer step,
+    running statistics) must invalidate them: the module then answers exactly like a fresh module loaded with the new state."""
+    from mocopci_amd import synth
+    x1, x2, _ = synth.make_batch(1, 1, 1024)
+    net = hc.build_model("cpu")
+    with torch.no_grad():
+        before = net(x1, x2)
+        sd = net.state_dict()
+        sd["multi_frame_inference.conv.3.weight"].mul_(1.5)          # folded with conv.4's BatchNorm in the fusion MLP
+        sd["multi_frame_inference.conv.4.running_var"].mul_(0.5)     # a buffer
+        after = net(x1, x2)
+        fresh = hc.build_model("cpu")
+        fresh.load_state_dict(net.state_dict())
+        want = fresh(x1, x2)
+    assert any(not torch.equal(a, b) for a, b in zip(before, after))
+    assert all(torch.equal(a, b) for a, b in zip(after, want))
