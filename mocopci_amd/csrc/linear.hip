@@ -6,8 +6,8 @@
 // LeakyReLU / PReLU / residual launches, and concatenates the inputs first (torch.cat of encoder, fusion and upsampled features,
 // mocopci.py:186-187, :846-847; Conv1d wrapper :1111-1127).  Here
 //   * a wave owns 32 rows on the MFMA column; the K loop runs in chunks of 32 input channels: the wave loads its own 32 x 32 tile
-//     of x straight from memory in accumulator layout (four float4 per lane), splits it (mfma_split.h) and multiplies it into
-//     n/32 accumulator tiles on the bf16 matrix pipe;
+//     of x with coalesced float4 reads, turns it into accumulator layout through a private LDS tile, splits it (mfma_split.h)
+//     and multiplies it into n/32 accumulator tiles on the bf16 matrix pipe;
 //   * the inputs may be up to three separate tensors with their own row strides (the pieces of a concatenation, or column
 //     slices of wider tensors): chunk c simply reads from the piece it falls into, nothing is concatenated;
 //   * the weight image ([chunk][out tile][k-step][piece][lane] x 16 B, split once by mcp_linear_pack) is streamed through LDS,
@@ -19,6 +19,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NW = 8, MAXSEG = 3;
 
 struct Segs {
@@ -30,6 +31,8 @@ struct Segs {
 
 // floats of one chunk image: NT out tiles x 2 k-steps x 3 pieces x 64 lanes x uint4
 __host__ __device__ constexpr int chunk_floats(int nt) { return nt * 2 * 3 * 64 * 4; }
+// floats of one LDS stage buffer: kc chunks rounded up to whole passes of the 512-thread workgroup (uint4 per thread per pass)
+__host__ __device__ constexpr size_t stage_floats(int nt, int kc) { return (size_t)((kc * chunk_floats(nt) / 4 + 511) / 512) * 512 * 4; }
 
 // W (n x ktot) row-major; the K axis is the concatenation of the pieces, each padded to a multiple of 32 in the image
 __global__ __launch_bounds__(256) void linear_pack_kernel(int n, int ktot, int nseg, int k0, int k1, int k2, const float *__restrict__ w,
@@ -63,17 +66,30 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(int n, int ktot, int n
     }
 }
 
-template <int NT>
+// KC: 32-channel chunks of the weight image per LDS stage (one barrier per stage).  With KC = 1 a long K at a narrow output is
+// bound by the hand-off (K = 536 -> 64: 17 barriers of 24 MFMAs each); KC = 2..4 divides that.
+// Rows sit on the MFMA column, so in operand layout a lane owns a K-slice of ONE row: read or written straight from memory
+// every lane of a load touches a different cache line (16 B of it), the lines of ~100 KB of tiles in flight per CU do not
+// survive in the 32 KB L1 until their other seven pieces are asked for, and the kernel moved 2.3 TB/s.  Both the x tiles and
+// the output tiles therefore go through a wave-private, padded LDS tile: global accesses are coalesced (8 lanes cover a row's
+// 128 B, 8 rows per instruction), the transposition to / from operand layout is four ds_write_b128 + four ds_read_b128 per tile.
+// No barrier is involved: a wave's LDS instructions execute in order.  x tiles are requested three chunks ahead.
+constexpr int XP = 36;              // floats per padded tile row (32 + 4: conflict-free for both access patterns)
+constexpr int XT = 32 * XP;         // one 32 x 32 tile
+
+template <int NT, int KC>
 __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int n, Segs sg, int nseg, int total_chunks, float slope,
                                                              const float *__restrict__ packed, const float *__restrict__ res, int rs_,
                                                              float *__restrict__ out, int os_) {
-    constexpr int CF = chunk_floats(NT), CH4 = CF / 4;
-    constexpr int LOADS = (CH4 + 64 * NW - 1) / (64 * NW);
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][CF]
+    constexpr int CF = chunk_floats(NT), CH4 = CF / 4;  // floats / uint4 per chunk
+    constexpr int LOADS = (KC * CH4 + 64 * NW - 1) / (64 * NW);
+    constexpr int SF = LOADS * 64 * NW * 4;  // floats per stage buffer: KC chunks, rounded up to whole passes of the workgroup
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // weights [2][SF] | tiles [NW][XT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
-    const long long row = ((long long)blockIdx.x * NW + wave) * 32 + col;
-    const bool live = row < rows;
-    const long long rr = live ? row : rows - 1;
+    const int cr = lane >> 3, cq = lane & 7;  // coalesced coordinates: row cr (+8j) of the tile, float4 number cq of its 32 channels
+    float *tile = lds + 2 * SF + wave * XT;  // one tile per wave is enough: a wave's LDS instructions execute in order, so the
+                                             // read of chunk c is done before the write of chunk c+1 lands on the same addresses
+    const long long row0 = ((long long)blockIdx.x * NW + wave) * 32;
 
     f32x16 acc[NT];
     {
@@ -83,79 +99,121 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = bi[(t * 2 + h) * 16 + r];
     }
-    uint4 pre[LOADS];
-    auto fetch = [&](int c) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(packed + (size_t)c * CF);
+    // Weight stage st = chunks KC*st .. KC*st + KC - 1 (the last one may be short): contiguous in the image.  Branch-free: a load
+    // under a branch makes the compiler wait for ALL outstanding loads (s_waitcnt vmcnt(0)) at every use, which serialises the
+    // whole prefetch pipeline; entries past the stage's end re-read its last one (never used).  Macros rather than lambdas: with
+    // the staging registers captured by reference the array ended up in scratch memory.
+    u32x4 pre[LOADS];  // native vector type: an array of HIP's uint4 structs here ended up in scratch memory
+#define LIN_FETCH(st_)                                                                                          \
+    {                                                                                                           \
+        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(packed + (size_t)(st_) * KC * CF);                  \
+        const int valid_ = min(KC, total_chunks - (st_) * KC) * CH4;                                            \
+        _Pragma("unroll") for (int u = 0; u < LOADS; ++u) pre[u] = src_[min(tid + u * 64 * NW, valid_ - 1)];    \
+    }
+#define LIN_STASH(buf_)                                                                                         \
+    {                                                                                                           \
+        u32x4 *dst_ = reinterpret_cast<u32x4 *>(lds + (size_t)(buf_) * SF);                                    \
+        _Pragma("unroll") for (int u = 0; u < LOADS; ++u) dst_[tid + u * 64 * NW] = pre[u];                     \
+    }
+    struct Tile { float4 v[4]; };
+    // rows past the end re-read the last row (their results are never stored)
+    long long xrow[4];
 #pragma unroll
-        for (int u = 0; u < LOADS; ++u) {
-            const int e = tid + u * 64 * NW;
-            if (e < CH4) pre[u] = src[e];
-        }
-    };
-    auto stash = [&](int buf) {
-        uint4 *dst = reinterpret_cast<uint4 *>(lds + (size_t)buf * CF);
+    for (int j = 0; j < 4; ++j) xrow[j] = min(row0 + 8 * j + cr, rows - 1);
+    // chunk `issued` of the concatenated K axis -> (piece, chunk within the piece) by comparisons with the pieces' first chunks:
+    // scalar selects, no branch, so the loop body stays one basic block (see fetch)
+    const int c1 = sg.chunks[0], c2 = c1 + (nseg > 1 ? sg.chunks[1] : 0);
+    int issued = 0;
+    auto request = [&](Tile &g) {
+        // Past the last chunk (a short last stage is padded to KC chunks) and past a piece's width the tile is zero: the load
+        // then re-reads the row's first float4 and the value is masked off -- an AND rather than a select, so that the compiler
+        // cannot turn it back into a load under a branch.
+        const bool live_chunk = issued < total_chunks;
+        const int ci = live_chunk ? issued : 0;
+        const int sgi = (ci >= c1) + (ci >= c2);
+        const int cci = ci - (sgi == 0 ? 0 : sgi == 1 ? c1 : c2);
+        const float *xb = sgi == 0 ? sg.x[0] : sgi == 1 ? sg.x[1] : sg.x[2];
+        const int stride = sgi == 0 ? sg.stride[0] : sgi == 1 ? sg.stride[1] : sg.stride[2];
+        const int kk = sgi == 0 ? sg.k[0] : sgi == 1 ? sg.k[1] : sg.k[2];
+        const bool ok = live_chunk && 32 * cci + 4 * cq < kk;  // channels of a piece are a multiple of 4
+        const uint32_t mask = ok ? 0xFFFFFFFFu : 0u;
+        const float *base = xb + (ok ? 32 * cci + 4 * cq : 0);
 #pragma unroll
-        for (int u = 0; u < LOADS; ++u) {
-            const int e = tid + u * 64 * NW;
-            if (e < CH4) dst[e] = pre[u];
+        for (int j = 0; j < 4; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(base + xrow[j] * stride);
+            g.v[j] = make_float4(__uint_as_float(v.x & mask), __uint_as_float(v.y & mask), __uint_as_float(v.z & mask), __uint_as_float(v.w & mask));
         }
+        ++issued;
     };
-    // this wave's 32 x 32 tile of x for chunk (seg, cc): registers 4g..4g+3 <- channels 32cc + 8g + 4h .. +3 (zero past the piece)
-    auto load_x = [&](int seg, int cc, f32x16 &a) {
-        const float *xr = sg.x[seg] + rr * sg.stride[seg] + 32 * cc;
-        const int kleft = sg.k[seg] - 32 * cc;
+    auto to_lds = [&](const Tile &g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(tile + (8 * j + cr) * XP + 4 * cq) = g.v[j];
+    };
+    // operand layout: registers 4g..4g+3 <- channels 8g + 4h .. +3 of row `col`
+    auto from_lds = [&](f32x16 &a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int ch = 8 * g + 4 * h;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ch < kleft) v = *reinterpret_cast<const float4 *>(xr + ch);
+            const float4 v = *reinterpret_cast<const float4 *>(tile + col * XP + 8 * g + 4 * h);
             a[4 * g + 0] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
         }
     };
-    int seg = 0, cc = 0;
-    f32x16 xa, xn;
-    load_x(0, 0, xa);
-    fetch(0);
-    stash(0);
-    for (int c = 0; c < total_chunks; ++c) {
-        const int cur = c & 1;
-        // next chunk's coordinates, weights and x tile are requested before this chunk is multiplied
-        int nseg_ = seg, ncc = cc + 1;
-        if (ncc >= sg.chunks[seg]) { nseg_ = seg + 1; ncc = 0; }
-        const bool more = c + 1 < total_chunks;
-        if (more) {
-            fetch(c + 1);
-            load_x(nseg_, ncc, xn);
-        }
-        __syncthreads();  // chunk c is complete in buffer cur; nobody reads buffer cur^1 any more
-        McpSplit3 xs[2];
-        xs[0] = mcp_split_kstep(xa, 0);
-        xs[1] = mcp_split_kstep(xa, 1);
-        const uint4 *wc = reinterpret_cast<const uint4 *>(lds + (size_t)cur * CF) + lane;
+    Tile ga, gb, gc;  // chunks c+1, c+2, c+3 while chunk c is multiplied
+    request(ga);
+    to_lds(ga);
+    request(ga);
+    request(gb);
+    LIN_FETCH(0)
+    LIN_STASH(0)
+    const int stages = (total_chunks + KC - 1) / KC;
+    for (int st = 0; st < stages; ++st) {
+        const int cur = st & 1;
+        // No branch in the loop body: the number of loads in flight at every wait is then a compile-time constant and the waits
+        // are exact counts.  The last stage fetches itself again (nobody reads the other buffer afterwards), and a short last
+        // stage runs all KC chunks: zero x tiles (request) against re-read, finite weights (fetch) add nothing.
+        LIN_FETCH(min(st + 1, stages - 1))
+        __syncthreads();  // stage st is complete in buffer cur; nobody reads buffer cur^1 any more
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mcp_tile_split<2>(wc + (size_t)t * 2 * 3 * 64, xs, acc[t]);
-        if (more) {
-            stash(cur ^ 1);
-            xa = xn;
-            seg = nseg_;
-            cc = ncc;
+        for (int k = 0; k < KC; ++k) {
+            request(gc);
+            f32x16 xa;
+            from_lds(xa);
+            to_lds(ga);  // the next chunk's tile (after the last chunk: zeros nobody uses)
+            ga = gb;
+            gb = gc;
+            McpSplit3 xs[2];
+            xs[0] = mcp_split_kstep(xa, 0);
+            xs[1] = mcp_split_kstep(xa, 1);
+            const uint4 *wc = reinterpret_cast<const uint4 *>(lds + (size_t)cur * SF + (size_t)k * CF) + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mcp_tile_split<2>(wc + (size_t)t * 2 * 3 * 64, xs, acc[t]);
         }
+        LIN_STASH(cur ^ 1)
     }
-    if (!live) return;
-    float *orow = out + row * os_;
-    const float *rrow = res ? res + row * rs_ : nullptr;
-    const bool vec = !(os_ & 3) && !(((uintptr_t)out) & 15) && !(rrow && ((rs_ & 3) || (((uintptr_t)res) & 15)));
+#undef LIN_FETCH
+#undef LIN_STASH
+    // epilogue: activation in registers, one 32-channel tile at a time through the wave's LDS tile, coalesced residual + store
+    const bool vec = !(os_ & 3) && !(((uintptr_t)out) & 15) && !(res && ((rs_ & 3) || (((uintptr_t)res) & 15)));
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int ch = 32 * t + 8 * g + 4 * h;
             float v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float a = acc[t][4 * g + u];
                 v[u] = a > 0.f ? a : a * slope;
             }
+            *reinterpret_cast<float4 *>(tile + col * XP + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        const int ch = 32 * t + 4 * cq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long row = row0 + 8 * j + cr;
+            const float4 v4 = *reinterpret_cast<const float4 *>(tile + (8 * j + cr) * XP + 4 * cq);
+            if (row >= rows || ch >= n) continue;
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            float *orow = out + row * os_;
+            const float *rrow = res ? res + row * rs_ : nullptr;
             if (vec && ch + 3 < n) {
                 if (rrow) {
                     const float4 r4 = *reinterpret_cast<const float4 *>(rrow + ch);
@@ -168,13 +226,15 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int 
                     if (ch + u < n) orow[ch + u] = v[u] + (rrow ? rrow[ch + u] : 0.f);
             }
         }
+    }
 }
 
-template <int NT>
-int launch_linear(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
-                  float *out, int os_, hipStream_t s) {
-    auto kern = linear_kernel<NT>;
-    const size_t lds = 2 * (size_t)chunk_floats(NT) * sizeof(float);
+template <int NT, int KC>
+int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
+                     float *out, int os_, hipStream_t s) {
+    auto kern = linear_kernel<NT, KC>;
+    const size_t lds = (2 * stage_floats(NT, KC) + (size_t)NW * XT) * sizeof(float);
+    static_assert((2 * stage_floats(NT, KC) + (size_t)NW * XT) * sizeof(float) <= 160 * 1024, "LDS budget");
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -182,6 +242,16 @@ int launch_linear(long long rows, int n, const Segs &sg, int nseg, int total_chu
     const long long groups = (rows + 32LL * NW - 1) / (32LL * NW);
     hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * NW), lds, s, rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_);
     return mcp_launch_status();
+}
+
+// stage depth by shape: long K gets KC chunks per barrier (two stages of 12 KB per chunk per 32 outputs beside the 36 KB of tiles)
+template <int NT>
+int launch_linear(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
+                  float *out, int os_, hipStream_t s) {
+    constexpr int KC = NT <= 2 ? 4 : NT <= 4 ? 2 : 1;
+    if (KC > 1 && total_chunks >= 2 * KC)
+        return launch_linear_kc<NT, KC>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+    return launch_linear_kc<NT, 1>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
 }
 
 int count_chunks(int nseg, const int *k) {

@@ -15,6 +15,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // floats per chunk image: W1 part (cin/16 k-steps), W2 part (cot out tiles x 2 k-steps), b1 (32, as [half][reg])
 __host__ __device__ constexpr int chunk_floats(int cin, int cot) { return ((cin / 16) * 3 * 64 + cot * 2 * 3 * 64) * 4 + 32; }
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp2_kernel(long long rows, int hi
                                                            float *__restrict__ out, int os_) {
     constexpr int K1 = CIN / 16, CF = chunk_floats(CIN, COT), CH4 = CF / 4;
     constexpr int LOADS = (CH4 + 64 * NW - 1) / (64 * NW);
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][CF]
+    constexpr int BUF = LOADS * 64 * NW * 4;  // floats per LDS buffer: one chunk image rounded up to whole passes of the workgroup
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][BUF]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     const int chunks = hidden / 32;
     const long long row = ((long long)blockIdx.x * NW + wave) * 32 + col;
@@ -94,30 +96,28 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp2_kernel(long long rows, int hi
             for (int r = 0; r < 16; ++r) acc_o[t][r] = b2i[(t * 2 + h) * 16 + r];
     }
 
-    uint4 pre[LOADS];
-    auto fetch = [&](int c) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(packed + (size_t)c * CF);
-#pragma unroll
-        for (int u = 0; u < LOADS; ++u) {
-            const int e = tid + u * 64 * NW;
-            if (e < CH4) pre[u] = src[e];
-        }
-    };
-    auto stash = [&](int buf) {
-        uint4 *dst = reinterpret_cast<uint4 *>(lds + (size_t)buf * CF);
-#pragma unroll
-        for (int u = 0; u < LOADS; ++u) {
-            const int e = tid + u * 64 * NW;
-            if (e < CH4) dst[e] = pre[u];
-        }
-    };
-    fetch(0);
-    stash(0);
+    // Staging registers of the next chunk's image.  Native vector type and no guards: as an array of HIP's uint4 structs written
+    // under `if (e < CH4)` the array lived in scratch memory and every load was followed by a full s_waitcnt vmcnt(0) -- the chunk
+    // hand-off then cost a memory round trip per chunk.  The LDS buffers are padded to whole passes of the workgroup, the source
+    // index is clamped (entries past the chunk re-read its last one and are never used).
+    u32x4 pre[LOADS];
+#define MLP_FETCH(c_)                                                                                                    \
+    {                                                                                                                    \
+        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(packed + (size_t)(c_) * CF);                                 \
+        _Pragma("unroll") for (int u = 0; u < LOADS; ++u) pre[u] = src_[min(tid + u * 64 * NW, CH4 - 1)];                \
+    }
+#define MLP_STASH(buf_)                                                                                                  \
+    {                                                                                                                    \
+        u32x4 *dst_ = reinterpret_cast<u32x4 *>(lds + (size_t)(buf_) * BUF);                                             \
+        _Pragma("unroll") for (int u = 0; u < LOADS; ++u) dst_[tid + u * 64 * NW] = pre[u];                              \
+    }
+    MLP_FETCH(0)
+    MLP_STASH(0)
     for (int c = 0; c < chunks; ++c) {
         const int cur = c & 1;
-        if (c + 1 < chunks) fetch(c + 1);
+        MLP_FETCH(min(c + 1, chunks - 1))  // the last chunk fetches itself again: no branch in the loop body
         __syncthreads();  // chunk c is complete in buffer cur; nobody reads buffer cur^1 any more
-        const float *img = lds + (size_t)cur * CF;
+        const float *img = lds + (size_t)cur * BUF;
         const uint4 *w1c = reinterpret_cast<const uint4 *>(img) + lane;
         const uint4 *w2c = w1c + (size_t)K1 * 3 * 64;
         f32x16 acc;
@@ -131,8 +131,10 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp2_kernel(long long rows, int hi
         hs[1] = mcp_split_kstep(acc, 1);
 #pragma unroll
         for (int t = 0; t < COT; ++t) acc_o[t] = mcp_tile_split<2>(w2c + (size_t)t * 2 * 3 * 64, hs, acc_o[t]);
-        if (c + 1 < chunks) stash(cur ^ 1);
+        MLP_STASH(cur ^ 1)
     }
+#undef MLP_FETCH
+#undef MLP_STASH
     if (!live) return;
     float *orow = out + row * os_;
     const float *rrow = res ? res + row * rs_ : nullptr;
@@ -160,7 +162,7 @@ template <int CIN, int COT, int NW>
 int launch_mlp2(long long rows, int hidden, int cout, float slope, const float *x, int xs_, const float *res, int rs_, const float *packed,
                 float *out, int os_, hipStream_t s) {
     auto kern = mlp2_kernel<CIN, COT, NW>;
-    const size_t lds = 2 * (size_t)chunk_floats(CIN, COT) * sizeof(float);
+    const size_t lds = 2 * (size_t)((chunk_floats(CIN, COT) / 4 + 64 * NW - 1) / (64 * NW)) * (64 * NW) * 4 * sizeof(float);
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -176,7 +178,7 @@ bool supported(int cin, int hidden, int cout) {
     // The shapes where the fused kernel beats the library chain (tools/mlp_ab.py, MI355X): C = 64 both heads (52 vs 88 us, 40 vs 74 us
     // at 49152 rows), C = 128 with a narrow output (81 vs 85 us at 24576 rows).  Measured and left to the library: 128 -> 512 -> 128
     // (118 vs 111 us) and 256 -> 1024 -> 3 (228 vs 116 us: 12288 rows are 48 workgroups' worth of work for this tiling).
-    return (cin == 64 && (cot == 1 || cot == 2)) || (cin == 128 && cot == 1);
+    return (cin == 64 && (cot == 1 || cot == 2)) || (cin == 128 && (cot == 1 || cot == 4));
 }
 
 }  // namespace
@@ -209,7 +211,8 @@ MCP_EXPORT int mcp_mlp2(long long rows, int cin, int hidden, int cout, float slo
     // 8 waves per workgroup share one streamed weight image (measured best: 4 is equal at C = 128, 2 is twice slower)
     if (cin == 64 && cot == 1) rc = launch_mlp2<64, 1, 8>(rows, hidden, cout, slope, x, x_stride, res, res_stride, packed, out, out_stride, s);
     else if (cin == 64) rc = launch_mlp2<64, 2, 8>(rows, hidden, cout, slope, x, x_stride, res, res_stride, packed, out, out_stride, s);
-    else rc = launch_mlp2<128, 1, 8>(rows, hidden, cout, slope, x, x_stride, res, res_stride, packed, out, out_stride, s);
+    else if (cot == 1) rc = launch_mlp2<128, 1, 8>(rows, hidden, cout, slope, x, x_stride, res, res_stride, packed, out, out_stride, s);
+    else rc = launch_mlp2<128, 4, 8>(rows, hidden, cout, slope, x, x_stride, res, res_stride, packed, out, out_stride, s);
     mcp_prof_end(MCP_KERNEL_MLP, s);
     return rc;
 }

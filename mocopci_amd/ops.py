@@ -399,20 +399,25 @@ class HipBackend:
 
     def linear_supported(self, xs, n):
         """Whether linear() takes this call.  Beyond what the kernel can do, a shape policy: the fused kernel beats the BLAS
-        chain for tall inputs with moderate K (tools/linear_ab.py, MI355X: 1.4-1.9x at rows >= 32768, K <= 280, e.g. 58 -> 32 us
-        for 196608 x 32 -> 64 + LeakyReLU) and loses for few rows (one 256-row workgroup per 8 waves: 2048-8192 rows do not cover
-        the chip) and for long K at narrow N (K = 536: 17 chunk hand-offs of 24 MFMAs each), which stay on the library."""
+        chain for tall inputs with moderate K (tools/linear_ab.py, MI355X: 1.3-1.9x at rows >= 16384, K <= 320, e.g. 58 -> 31 us
+        for 196608 x 32 -> 64 + LeakyReLU) and, since its K loop is staged four chunks per barrier, for the K = 536 -> 64 PointConv
+        projections (171 -> 146 us at 196608 rows); it loses for few rows (one 256-row workgroup per 8 waves: 2048-8192 rows do
+        not cover the chip) and for long K at wide N (2072 -> 256), which stay on the library."""
         if self._NO_LINEAR:
             return False
         ps = self._pieces(xs)
         if ps is None or len(ps) > 3 or len({p.shape[0] for p in ps}) != 1:
             return False
-        if ps[0].shape[0] < 16384 or sum(p.shape[1] for p in ps) > 320 or n > 192:
+        k = sum(p.shape[1] for p in ps)
+        if ps[0].shape[0] < self._LIN_MIN_ROWS or n > self._LIN_MAX_N or (k > self._LIN_MAX_K and not (k <= 2 * self._LIN_MAX_K and n <= 64)):
             return False
         ks = (ctypes.c_int * len(ps))(*[p.shape[1] for p in ps])
         return _lib.load().mcp_linear_packed_floats(n, len(ps), ks) != 0
 
     _NO_LINEAR = os.environ.get("MCP_NO_LINEAR", "0") == "1"
+    _LIN_MIN_ROWS = int(os.environ.get("MCP_LINEAR_MIN_ROWS", "16384"))
+    _LIN_MAX_K = int(os.environ.get("MCP_LINEAR_MAX_K", "320"))
+    _LIN_MAX_N = int(os.environ.get("MCP_LINEAR_MAX_N", "192"))
 
     def linear_pack(self, w, b, ks):
         """Operand image of one Linear whose K axis is the concatenation of pieces of widths ks (split once per layer)."""

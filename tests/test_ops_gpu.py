@@ -567,7 +567,8 @@ def test_mlp2_matches_unfused_oracle(cin, hidden, cout, rows, with_res):
 
 
 @pytest.mark.parametrize("rows,ks,n,slope,with_res", [(20000, (64,), 64, 0.1, False), (16390, (280,), 32, 0.1, False), (17000, (64, 64, 64), 64, 1.0, True),
-                                                      (16384, (32,), 192, 0.0, False), (33000, (128,), 100, 0.25, True)])
+                                                      (16384, (32,), 192, 0.0, False), (33000, (128,), 100, 0.25, True),
+                                                      (16500, (536,), 64, 0.1, False), (16384, (300, 200, 36), 40, 1.0, True)])
 def test_linear_matches_unfused_oracle(rows, ks, n, slope, with_res):
     """Fused per-point Linear (Conv1d wrapper mocopci.py:1111-1127 + the concatenation in front of it) against the oracle backend's
     cat - Linear - activation - residual; one piece is read through a row stride (a column slice of a wider tensor)."""
@@ -585,7 +586,8 @@ def test_linear_matches_unfused_oracle(rows, ks, n, slope, with_res):
     got = be.linear(xd if len(xd) > 1 else xd[0], w.to(DEV), b.to(DEV), slope, None if res is None else res.to(DEV))
     torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
     # shapes outside the policy are declined (the caller then takes the BLAS chain)
-    assert not be.linear_supported(xd[0][:2048], n) and not be.linear_supported(torch.empty(20000, 600, device=DEV), 64)
+    assert not be.linear_supported(xd[0][:2048], n) and not be.linear_supported(torch.empty(20000, 700, device=DEV), 64)
+    assert not be.linear_supported(torch.empty(20000, 600, device=DEV), 128)
 
 
 def test_cross_volume_batch_map_equals_replicated_inputs():

@@ -15,6 +15,8 @@ for rows, c, h, co in ((49152, 64, 256, 64), (49152, 64, 256, 3), (24576, 128, 5
     w1, b1 = torch.randn(h, c, device="cuda") / c ** 0.5, torch.randn(h, device="cuda") * 0.1
     w2, b2 = torch.randn(co, h, device="cuda") / h ** 0.5, torch.randn(co, device="cuda") * 0.1
     a = torch.tensor([0.25], device="cuda")
+    if not be.mlp2_supported(c, h, co):
+        print(f"rows {rows:6d} {c:3d}->{h:4d}->{co:3d}: unsupported"); continue
     pk = be.mlp2_pack(w1, b1, w2, b2)
     lib = lambda: F.linear(F.prelu(F.linear(x, w1, b1), a), w2, b2) + res
     fused = lambda: be.mlp2(x, w1, b1, w2, b2, 0.25, res=res, packed=pk)
