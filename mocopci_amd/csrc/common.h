@@ -87,6 +87,15 @@ static inline int mcp_launch_status() {
 }
 static inline unsigned mcp_divup(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// Quotient of a flat index.  gfx950 has no integer divider: a 64-bit division is ~130 VALU instructions, a 32-bit one ~25 -- for
+// a gather kernel that moves one float4 per thread, or a per-point loop of a few hundred instructions, the 64-bit form IS the
+// kernel.  `fits32` = "the largest dividend fits 32 bits" (a kernel argument, so the branch is wave-uniform; true for every
+// shape of this pipeline), the 64-bit path keeps very large launches correct.
+__device__ __forceinline__ long long mcp_div(long long a, int b, bool fits32) {
+    return fits32 ? (long long)((uint32_t)a / (uint32_t)b) : a / b;
+}
+__device__ __forceinline__ bool mcp_fits32(long long total) { return total <= 0xFFFFFFFFLL; }
+
 // Raw max / min / relu.  fmaxf()/fminf() first canonicalise any operand the compiler cannot prove quiet (MFMA results,
 // loads, DPP outputs): an extra v_max_f32 x,x per operand.  The kernels' values are never signalling NaNs, so the
 // hot loops use the bare instructions.  NEVER feed these an MFMA result directly: the compiler does not see into the

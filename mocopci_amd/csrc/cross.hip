@@ -31,6 +31,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KNB = 32;
 constexpr float SLOPE = 0.1f;  // pointconv_util.py:10
+constexpr int MAX_MAPPED_BATCH = 1024;  // batch elements a batch map may have (it is kept in LDS)
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // LeakyReLU with 0 < slope < 1 is max(v, slope*v): two instructions, same value for every finite v (and for +-0)
@@ -153,75 +154,82 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
         reinterpret_cast<float4 *>(lds)[e] = reinterpret_cast<const float4 *>(packed + L::OFF_W + (size_t)split * WH)[e];
     for (int e = tid; e < SMALL / 4; e += 64 * WAVES)
         reinterpret_cast<float4 *>(lds + WH)[e] = reinterpret_cast<const float4 *>(packed + L::OFF_POS)[e];
+    if (bmap) {
+        const int nb = (int)(total / n1);  // <= MCP_CROSS_MAX_MAPPED_BATCH (checked by the host)
+        for (int e = tid; e < nb; e += 64 * WAVES) reinterpret_cast<int *>(lds + WH + SMALL + WAVES * D)[e] = bmap[e];
+    }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     const float4 *wq = reinterpret_cast<const float4 *>(lds);
     const float *lpos = lds + WH, *lbias = lds + WH + L::POS_FLOATS;
+    float *row1_lds = lds + WH + SMALL + wave * D;               // this wave's copy of the current point's points1 row
+    const int *bmap_lds = reinterpret_cast<const int *>(lds + WH + SMALL + WAVES * D);
 
-    // Software pipeline over the wave's points: the neighbour index of point i+2 and the gathered rows of point i+1 are
-    // in flight while the D x D layer of point i runs on the MFMA pipe (the row registers are free again once layer 1
-    // has consumed them), so the idx -> gather -> MFMA latency chain is paid once per wave, not once per point.
+    // Software pipeline over the wave's points: the neighbour index of point i+2 and every load of point i+1 (coordinates, the
+    // gathered rows of points2, the row of points1) are in flight while the D x D layer of point i runs on the MFMA pipe, so the
+    // idx -> gather -> MFMA latency chain is paid once per wave, not once per point.  For that to hold nothing may WAIT between
+    // issue and the next iteration: the prefetch step only issues loads and keeps the raw values (the coordinate differences are
+    // formed where they are consumed), the batch map is read from LDS (a global lookup feeding an address would be a dependent
+    // round trip in the middle of the issue sequence), and the points1 row -- the same 4 D bytes for all 32 neighbours -- is one
+    // float4 per lane that goes through a wave-private LDS row into accumulator layout instead of 4 T broadcast loads per lane.
     const long long stride = (long long)gridDim.x * WAVES;
     long long p = (long long)blockIdx.x * WAVES + wave;
-    float in0 = 0.f, in1 = 0.f;
-    // gathered points2 row and (D = 64 only: at D = 128 it would spill) points1 row, both in accumulator layout
-    constexpr bool PRE_A = D <= 64;
-    float4 ra[PRE_A ? T : 1][4], rg[T][4];
+    float q2x = 0.f, q2y = 0.f, q2z = 0.f, p1x = 0.f, p1y = 0.f, p1z = 0.f;  // raw coordinates of the point in flight
+    float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);                               // float4 number `lane` of its points1 row (lane < D/4)
+    float4 rg[T][4];                                                          // its gathered points2 row, accumulator layout
     // bmap != NULL: the batch is a replication / selection of a smaller one (the three flow iterations of multiframe_attention see
     // the same features): batch element bb of the tensors flagged in `shared` (1: points1, 2: points2, 4: the first index list)
     // is read from element bmap[bb] of the unreplicated tensor -- nothing is copied.  xyz1 / xyz2 and the second list are per element.
-    auto src1 = [&](long long pp) {  // row of points1 for point pp
-        if (!(bmap && (shared & 1))) return pp;
-        const long long bb = pp / n1;
-        return (long long)bmap[bb] * n1 + (pp - bb * n1);
+    auto mapped = [&](int bb, int flag) -> long long { return (bmap && (shared & flag)) ? (long long)bmap_lds[bb] : (long long)bb; };
+    // (batch element, point within it) of the wave's points, advanced by additions: a 64-bit division per point and per lookup
+    // is ~130 instructions, as much issue time as the whole D = 64 MFMA block
+    struct Pos { int bb, off; };
+    const int stride_b = (int)(stride / n1), stride_o = (int)(stride % n1);
+    auto advance = [&](Pos q) {
+        q.bb += stride_b;
+        q.off += stride_o;
+        if (q.off >= n1) { q.off -= n1; ++q.bb; }
+        return q;
     };
-    long long r1next = 0;
-    auto fetch = [&](long long pp, int id) {
-        const long long bb = pp / n1;
-        const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
-        const float dx = q2[0] - xyz1[pp * 3 + 0], dy = q2[1] - xyz1[pp * 3 + 1], dz = q2[2] - xyz1[pp * 3 + 2];
-        in0 = h ? dy : dx;
-        in1 = h ? 1.0f : dz;
-        const long long b2 = (bmap && (shared & 2)) ? bmap[bb] : bb;
-        const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)b2 * n2 + id) * D);
-        r1next = src1(pp);  // kept for the accumulator initialisation of that point (no second map lookup on its critical path)
-        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + r1next * D);
+    auto fetch = [&](long long pp, Pos q, int id) {
+        const float *q2 = xyz2 + ((long long)q.bb * n2 + id) * 3;
+        q2x = q2[0]; q2y = q2[1]; q2z = q2[2];
+        p1x = xyz1[pp * 3 + 0]; p1y = xyz1[pp * 3 + 1]; p1z = xyz1[pp * 3 + 2];
+        const float4 *row2 = reinterpret_cast<const float4 *>(points2 + (mapped(q.bb, 2) * n2 + id) * D);
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + (mapped(q.bb, 1) * n1 + q.off) * D);
+        r1 = row1[lane < D / 4 ? lane : 0];
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {  // channels 32t + 8g + 4h .. +3  ->  registers 4g .. 4g+3
-                if (PRE_A) ra[t][g] = row1[(32 * t + 8 * g + 4 * h) >> 2];
-                rg[t][g] = row2[(32 * t + 8 * g + 4 * h) >> 2];
-            }
+            for (int g = 0; g < 4; ++g) rg[t][g] = row2[(32 * t + 8 * g + 4 * h) >> 2];  // channels 32t + 8g + 4h .. +3 -> registers 4g .. 4g+3
     };
     // idx2 != NULL: the 16 feature-space and the 16 coordinate-space neighbours come as two (B,N1,16) lists
-    auto nbr = [&](long long pp) {
+    auto nbr = [&](long long pp, Pos q) {
         if (!idx2) return idx[pp * KNB + col];
-        if (col >= 16) return idx2[pp * 16 + col - 16];
-        long long ps = pp;
-        if (bmap && (shared & 4)) {
-            const long long bb = pp / n1;
-            ps = (long long)bmap[bb] * n1 + (pp - bb * n1);
-        }
-        return idx[ps * 16 + col];
+        const long long ps = mapped(q.bb, 4) * n1 + q.off;
+        return col >= 16 ? idx2[pp * 16 + col - 16] : idx[ps * 16 + col];
     };
     long long pn = p + stride;
+    Pos qp{(int)(p / n1), (int)(p % n1)};
+    Pos qn = advance(qp), qnn = advance(qn);
     int idn = 0;
     if (p < total) {
-        fetch(p, nbr(p));
-        if (pn < total) idn = nbr(pn);
+        fetch(p, qp, nbr(p, qp));
+        if (pn < total) idn = nbr(pn, qn);
     }
     for (; p < total; p = pn, pn += stride) {
         f32x16 x0[L::BF ? 1 : T];
         McpSplit3 xs[L::BF ? 2 * T : 1];
-        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + r1next * D);  // set by the fetch of this point
+        const float in0 = h ? q2y - p1y : q2x - p1x, in1 = h ? 1.0f : q2z - p1z;  // k-step 0: (dx,dy); k-step 1: (dz,1)
+        if (lane < D / 4) reinterpret_cast<float4 *>(row1_lds)[lane] = r1;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             f32x16 acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 a = PRE_A ? ra[t][g] : row1[(32 * t + 8 * g + 4 * h) >> 2];
+                const float4 a = reinterpret_cast<const float4 *>(row1_lds)[(32 * t + 8 * g + 4 * h) >> 2];
                 acc[4 * g + 0] = a.x; acc[4 * g + 1] = a.y; acc[4 * g + 2] = a.z; acc[4 * g + 3] = a.w;
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lpos[(t * 2 + 0) * 64 + lane], in0, acc, 0, 0, 0);
@@ -240,10 +248,13 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
                 x0[L::BF ? 0 : t] = acc;
             }
         }
+        __builtin_amdgcn_wave_barrier();  // the row has been read: the next point's may be written over it
         if (pn < total) {
-            fetch(pn, idn);
-            if (pn + stride < total) idn = nbr(pn + stride);
+            fetch(pn, qn, idn);
+            if (pn + stride < total) idn = nbr(pn + stride, qnn);
         }
+        qn = qnn;
+        qnn = advance(qnn);
 #pragma unroll 1
         for (int tl = 0; tl < TO; ++tl) {
             const int t = TO * split + tl;
@@ -274,13 +285,14 @@ template <int D, int SPLIT>
 int launch_cross(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
                  const int *idx, const int *idx2, const int *bmap, int shared, const float *packed, float *out, hipStream_t s) {
     using L = CrossLds<D>;
-    const size_t lds = (L::W_FLOATS / SPLIT + L::POS_FLOATS + L::B_FLOATS) * sizeof(float);
+    constexpr int WAVES = CrossShape<D>::NW;
+    // weights | pos + bias | one points1 row per wave | the batch map (only when one is passed)
+    const size_t lds = (L::W_FLOATS / SPLIT + L::POS_FLOATS + L::B_FLOATS + WAVES * D + (bmap ? MAX_MAPPED_BATCH : 0)) * sizeof(float);
     auto kern = cross_kernel<D, SPLIT>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    constexpr int WAVES = CrossShape<D>::NW;
     // at least 8 points per wave so the weight staging is amortised
     const long long want = (total + WAVES * 8 - 1) / (WAVES * 8);
     // persistent-style grid = exactly the resident slots (256 CUs x 3 or 2 workgroups, see __launch_bounds__): a larger
@@ -314,6 +326,7 @@ MCP_EXPORT int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float
     MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && packed && out);
     if (k != KNB || (d != 64 && d != 128 && d != 256)) return MCP_ERR_UNSUPPORTED;
     if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)out) | ((uintptr_t)packed)) & 15) return MCP_ERR_BAD_ARG;
+    if (bmap && b > MAX_MAPPED_BATCH) return MCP_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)b * n1;
     mcp_prof_begin(MCP_KERNEL_CROSS, s);

@@ -44,9 +44,9 @@ __global__ __launch_bounds__(BLK) void interp3_apply_kernel(int n, int s, int cv
     long long g = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long stride = (long long)gridDim.x * BLK;
     for (; g < total; g += stride) {
-        const long long row = g / cv;  // b*n + p
+        const long long row = mcp_div(g, cv, mcp_fits32(total));  // b*n + p
         const int col = (int)(g - row * cv);
-        const int b = (int)(row / n);
+        const int b = (int)mcp_div(row, n, mcp_fits32(total));
         const int *id = idx3 + row * 3;
         const float *w = w3 + row * 3;
         const float w0 = w[0], w1 = w[1], w2 = w[2];
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(BLK) void interp3_apply_grad_kernel(int n, int s, i
     long long g = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long stride = (long long)gridDim.x * BLK;
     for (; g < total; g += stride) {
-        const long long row = g / c;  // b*n + p
+        const long long row = mcp_div(g, c, mcp_fits32(total));  // b*n + p
         const int col = (int)(g - row * c);
-        const int b = (int)(row / n);
+        const int b = (int)mcp_div(row, n, mcp_fits32(total));
         const float go = grad_out[g];
 #pragma unroll
         for (int j = 0; j < 3; ++j)

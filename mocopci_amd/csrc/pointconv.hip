@@ -29,13 +29,14 @@ __global__ __launch_bounds__(THREADS) void pointconv_agg_kernel(long long total,
     __shared__ int il[PPB][K];
     const int tid = threadIdx.x;
     const int cin = d + 3;
+    const bool f32 = mcp_fits32(total);
     for (long long p0 = (long long)blockIdx.x * PPB; p0 < total; p0 += (long long)gridDim.x * PPB) {
         __syncthreads();
         {   // ---- phase 1 ----
             const int pl = tid >> 5, k = tid & 31;
             const long long p = p0 + pl;
             if (p < total) {
-                const long long bb = p / s;
+                const long long bb = mcp_div(p, s, f32);
                 const int id = idx[p * K + k];
                 const float *q = s_xyz + ((long long)bb * n + id) * 3;
                 const float x0 = q[0] - new_xyz[p * 3 + 0], x1 = q[1] - new_xyz[p * 3 + 1], x2 = q[2] - new_xyz[p * 3 + 2];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(THREADS) void pointconv_agg_kernel(long long total,
             const int pl = it / cin, c = it - pl * cin;
             const long long p = p0 + pl;
             if (p >= total) break;
-            const long long bb = p / s;
+            const long long bb = mcp_div(p, s, f32);
             float acc[WN];
 #pragma unroll
             for (int j = 0; j < WN; ++j) acc[j] = 0.f;

@@ -72,9 +72,9 @@ __global__ __launch_bounds__(BLK) void group_rows_kernel(int n, int cv, long lon
     long long g = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long stride = (long long)gridDim.x * BLK;
     for (; g < total; g += stride) {
-        const long long row = g / cv;
+        const long long row = mcp_div(g, cv, mcp_fits32(total));
         const int col = (int)(g - row * cv);
-        const int b = (int)(row / t);
+        const int b = (int)mcp_div(row, t, mcp_fits32(total));
         const int src = idx[row];
         out[g] = points[((long long)b * n + src) * cv + col];
     }
@@ -88,10 +88,10 @@ __global__ __launch_bounds__(BLK) void group_rows_add_leaky_kernel(int n, int cv
     long long g = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long stride = (long long)gridDim.x * BLK;
     for (; g < total; g += stride) {
-        const long long row = g / cv;  // b*S*K + s*K + j
+        const long long row = mcp_div(g, cv, mcp_fits32(total));  // b*S*K + s*K + j
         const int col = (int)(g - row * cv);
-        const int b = (int)(row / sk);
-        const float4 p = points[((long long)b * n + idx[row]) * cv + col], c = centre[(row / k) * cv + col];
+        const int b = (int)mcp_div(row, sk, mcp_fits32(total));
+        const float4 p = points[((long long)b * n + idx[row]) * cv + col], c = centre[mcp_div(row, k, mcp_fits32(total)) * cv + col];
         float4 o = make_float4(p.x + c.x, p.y + c.y, p.z + c.z, p.w + c.w);
         o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
         o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(BLK) void group_rows_grad_kernel(int n, int c, long
     long long g = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long stride = (long long)gridDim.x * BLK;
     for (; g < total; g += stride) {
-        const long long row = g / c;
+        const long long row = mcp_div(g, c, mcp_fits32(total));
         const int col = (int)(g - row * c);
-        const int b = (int)(row / t);
+        const int b = (int)mcp_div(row, t, mcp_fits32(total));
         atomicAdd(grad_points + ((long long)b * n + idx[row]) * c + col, grad_out[g]);
     }
 }
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(BLK) void group_rows_grad_sorted_kernel(int n, int 
     long long g = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long stride = (long long)gridDim.x * BLK;
     for (; g < total; g += stride) {
-        const long long row = g / cw;  // b * n + destination
+        const long long row = mcp_div(g, cw, mcp_fits32(total));  // b * n + destination
         const int col = (int)(g - row * cw);
-        const int b = (int)(row / n), d = (int)(row - (long long)b * n);
+        const int b = (int)mcp_div(row, n, mcp_fits32(total)), d = (int)(row - (long long)b * n);
         const int *sg = seg + (long long)b * (n + 1) + d;
         const int lo = sg[0], hi = sg[1];
         const int *ord = order + (long long)b * t;

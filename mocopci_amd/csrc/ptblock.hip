@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ptblock_kernel(long long total,
         long long p = 2 * pp + sel;
         const bool live = p < total;
         if (!live) p = total - 1;  // odd tail: the second half of the wave recomputes the last point and does not store
-        const long long bb = p / n;
+        const long long bb = mcp_div(p, n, mcp_fits32(total));
         const int id = idx[p * KNB + j];
         const float *cj = xyz + ((long long)bb * n + id) * 3;
         const float dx = xyz[p * 3 + 0] - cj[0], dy = xyz[p * 3 + 1] - cj[1], dz = xyz[p * 3 + 2] - cj[2];  // xyz_i - xyz_j
