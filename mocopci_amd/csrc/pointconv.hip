@@ -30,6 +30,7 @@ __global__ __launch_bounds__(THREADS) void pointconv_agg_kernel(long long total,
     const int tid = threadIdx.x;
     const int cin = d + 3;
     const bool f32 = mcp_fits32(total);
+    const bool off32 = (long long)n * d < (1LL << 31);
     for (long long p0 = (long long)blockIdx.x * PPB; p0 < total; p0 += (long long)gridDim.x * PPB) {
         __syncthreads();
         {   // ---- phase 1 ----
@@ -66,19 +67,22 @@ __global__ __launch_bounds__(THREADS) void pointconv_agg_kernel(long long total,
         }
         __syncthreads();
         // ---- phase 2 ----
-        const int items = PPB * cin;
-        for (int it = tid; it < items; it += THREADS) {
-            const int pl = it / cin, c = it - pl * cin;
+        // Feature channels and coordinate channels are separate loops: one loop with `c < 3 ? LDS : global` per neighbour made the
+        // compiler merge the two sources into FLAT loads behind a pointer select -- a divergent branch per neighbour and waits
+        // that drain the LDS and the global queue together.
+        for (int it = tid; it < PPB * d; it += THREADS) {
+            const int pl = it / d, c = it - pl * d;
             const long long p = p0 + pl;
             if (p >= total) break;
             const long long bb = mcp_div(p, s, f32);
             float acc[WN];
 #pragma unroll
             for (int j = 0; j < WN; ++j) acc[j] = 0.f;
-            const float *fb = s_points + (long long)bb * n * d + (c - 3);
-#pragma unroll 4
+            const float *fb = s_points + (long long)bb * n * d + c;
+#pragma unroll 8
             for (int k = 0; k < K; ++k) {
-                const float f = c < 3 ? gx[pl][k][c] : fb[(long long)il[pl][k] * d];
+                // row offsets within one batch element fit 32 bits whenever n * d does (checked by the host: off32)
+                const float f = off32 ? fb[(unsigned)il[pl][k] * (unsigned)d] : fb[(long long)il[pl][k] * d];
                 const float4 wa = *reinterpret_cast<const float4 *>(&wl[pl][k][0]);
                 const float4 wb = *reinterpret_cast<const float4 *>(&wl[pl][k][4]);
                 acc[0] = __builtin_fmaf(f, wa.x, acc[0]); acc[1] = __builtin_fmaf(f, wa.y, acc[1]);
@@ -86,9 +90,31 @@ __global__ __launch_bounds__(THREADS) void pointconv_agg_kernel(long long total,
                 acc[4] = __builtin_fmaf(f, wb.x, acc[4]); acc[5] = __builtin_fmaf(f, wb.y, acc[5]);
                 acc[6] = __builtin_fmaf(f, wb.z, acc[6]); acc[7] = __builtin_fmaf(f, wb.w, acc[7]);
             }
-            float4 *o = reinterpret_cast<float4 *>(out + (p * cin + c) * WN);
+            float4 *o = reinterpret_cast<float4 *>(out + (p * cin + 3 + c) * WN);
             o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        if (tid < PPB * 3) {  // the three coordinate channels of every point: dxyz from LDS
+            const int pl = tid / 3, c = tid - pl * 3;
+            const long long p = p0 + pl;
+            if (p < total) {
+                float acc[WN];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[j] = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < K; ++k) {
+                    const float f = gx[pl][k][c];
+                    const float4 wa = *reinterpret_cast<const float4 *>(&wl[pl][k][0]);
+                    const float4 wb = *reinterpret_cast<const float4 *>(&wl[pl][k][4]);
+                    acc[0] = __builtin_fmaf(f, wa.x, acc[0]); acc[1] = __builtin_fmaf(f, wa.y, acc[1]);
+                    acc[2] = __builtin_fmaf(f, wa.z, acc[2]); acc[3] = __builtin_fmaf(f, wa.w, acc[3]);
+                    acc[4] = __builtin_fmaf(f, wb.x, acc[4]); acc[5] = __builtin_fmaf(f, wb.y, acc[5]);
+                    acc[6] = __builtin_fmaf(f, wb.z, acc[6]); acc[7] = __builtin_fmaf(f, wb.w, acc[7]);
+                }
+                float4 *o = reinterpret_cast<float4 *>(out + (p * cin + c) * WN);
+                o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
         }
     }
 }

@@ -89,12 +89,23 @@ __device__ __forceinline__ float mcp_tau_of(mcp_key kth) { return mcp_key_is_inf
 // drain a lane's queue ([slot][lane] of (distance bits, index)) into its K-list
 template <int K, int QS>
 __device__ __forceinline__ void mcp_flush_queue(mcp_key (&a)[K], const uint2 (*queue)[64], int lane, int cnt) {
+    // All QS reads are issued back to back and pinned above the selects by one empty asm statement.  Left alone the compiler
+    // sinks every read under its own `s < cnt` branch: QS divergent branches, each with its own round trip to LDS.
+    static_assert(QS == 4 || QS == 8 || QS == 16, "the pin below lists its operands");
+    unsigned long long e[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) e[s] = *reinterpret_cast<const unsigned long long *>(&queue[s][lane]);
+    if constexpr (QS == 16)
+        asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]),
+                     "+v"(e[9]), "+v"(e[10]), "+v"(e[11]), "+v"(e[12]), "+v"(e[13]), "+v"(e[14]), "+v"(e[15]));
+    else if constexpr (QS == 8)
+        asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]));
+    else
+        asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
     mcp_key qk[QS];
 #pragma unroll
-    for (int s = 0; s < QS; ++s) {
-        const uint2 e = queue[s][lane];
-        qk[s] = s < cnt ? mcp_make_key(__uint_as_float(e.x), e.y) : MCP_KEY_INF;
-    }
+    for (int s = 0; s < QS; ++s)
+        qk[s] = s < cnt ? mcp_make_key(__uint_as_float((uint32_t)e[s]), (uint32_t)(e[s] >> 32)) : MCP_KEY_INF;
     mcp_bitonic_sort<QS>(qk);
     mcp_merge_sorted<K, QS>(a, qk);
 }
