@@ -70,3 +70,41 @@ def test_mlp2_is_deterministic():
     pk = be.mlp2_pack(rnd(256, 64, scale=0.125), rnd(256, scale=0.1), rnd(64, 256, scale=0.06), rnd(64, scale=0.1))
     w = (rnd(256, 64), rnd(256), rnd(64, 256), rnd(64))  # shapes only: the packed image carries the values
     assert repeatable(lambda: be.mlp2(x, *w, 0.25, res=res, packed=pk))
+
+
+def test_cross_kernel_with_batch_map_is_deterministic():
+    """The replicated-batch form the inference graph uses (features and the first index list read through a batch map)."""
+    torch.manual_seed(5)
+    be = ops.backend()
+    B0, R, n, d = 16, 3, 2048, 64
+    B = B0 * R
+    x1, x2 = rnd(B, n, 3, scale=10.0), rnd(B, n, 3, scale=10.0)
+    f1, f2 = rnd(B0, n, d), rnd(B0, n, d)
+    ic = torch.randint(0, n, (B0, n, 16), device=DEV, dtype=torch.int32)
+    ip = torch.randint(0, n, (B, n, 16), device=DEV, dtype=torch.int32)
+    bmap = torch.tensor([i % B0 for i in range(B)], device=DEV, dtype=torch.int32)
+    pk = be.cross_pack(rnd(d, 3, scale=0.3), rnd(d, scale=0.1), rnd(d, d, scale=d ** -0.5), rnd(d, scale=0.1))
+    assert repeatable(lambda: be.cross_volume(x1, x2, f1, f2, (ic, ip), pk, bmap=bmap, shared=7))
+
+
+def test_linear_pointconv_and_small_attention_are_deterministic():
+    torch.manual_seed(6)
+    be = ops.backend()
+    x = rnd(196608, 536)
+    w, b = rnd(64, 536, scale=536 ** -0.5), rnd(64, scale=0.1)
+    pk = be.linear_pack(w, b, [536])
+    assert repeatable(lambda: be.linear(x, w, b, 0.1, None, packed=pk))
+    xs = [rnd(32768, 64), rnd(32768, 64), rnd(32768, 64)]
+    w3, res = rnd(64, 192, scale=192 ** -0.5), rnd(32768, 64)
+    assert repeatable(lambda: be.linear(xs, w3, b, 1.0, res))
+    # PointConv aggregation at level 0 of the pipeline
+    B, n = 16, 8192
+    xyz, feat = rnd(B, n, 3, scale=10.0), rnd(B, n, 32)
+    idx = torch.randint(0, n, (B, n, 32), device=DEV, dtype=torch.int32)
+    wn = [rnd(8, 3, scale=0.5), rnd(8, scale=0.1), rnd(8, 8, scale=0.4), rnd(8, scale=0.1), rnd(8, 8, scale=0.4), rnd(8, scale=0.1)]
+    assert repeatable(lambda: be.pointconv_agg(xyz, xyz, feat, idx, *wn))
+    # head dims 8 / 16 (Multi_Frame_Att at the two pyramid levels)
+    q, kv = rnd(48, 2048, 64), rnd(48, 2048, 128)
+    assert repeatable(lambda: be.attention(q, kv, 8))
+    q, kv = rnd(48, 512, 128), rnd(48, 512, 256)
+    assert repeatable(lambda: be.attention(q, kv, 8))
