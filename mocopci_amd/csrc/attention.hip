@@ -20,7 +20,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f2 __attribute__((ext_vector_type(2)));
+typedef mcp_f2 f2;  // scalar pair: see common.h (no packed-fp32 instructions)
 constexpr int WAVES = 4, KT = 64;  // keys per LDS stage (two 32-key MFMA tiles)
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_kernel(int nq, int
             l *= alpha;
             const f2 alpha2 = {alpha, alpha};
 #pragma unroll
-            for (int d = 0; d < HD / 2; ++d) o[d] *= alpha2;
+            for (int d = 0; d < HD / 2; ++d) o[d] = o[d] * alpha2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(acc[r] - mn);
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_kernel(int nq, int
 #pragma unroll
                 for (int d = 0; d < HD; d += 4) {
                     const float4 vv = *reinterpret_cast<const float4 *>(vr + d);
-                    o[d / 2 + 0] = __builtin_elementwise_fma(p2, f2{vv.x, vv.y}, o[d / 2 + 0]);
-                    o[d / 2 + 1] = __builtin_elementwise_fma(p2, f2{vv.z, vv.w}, o[d / 2 + 1]);
+                    o[d / 2 + 0] = mcp_f2_fma(p2, f2{vv.x, vv.y}, o[d / 2 + 0]);
+                    o[d / 2 + 1] = mcp_f2_fma(p2, f2{vv.z, vv.w}, o[d / 2 + 1]);
                 }
             }
         }

@@ -87,6 +87,20 @@ static inline int mcp_launch_status() {
 }
 static inline unsigned mcp_divup(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// A pair of floats with element-wise arithmetic -- deliberately NOT an ext-vector type, and the library is built with
+// -fno-slp-vectorize: no packed-fp32 instruction (v_pk_add/mul/fma_f32) may be formed.  On MI355X (ROCm 7.2 compiler) kernels
+// using them returned wrong values, rarely and timing-dependently, while a bf16-MFMA-heavy kernel of another stream shared the
+// chip: furthest point sampling picked different points in ~8 % of its launches beside the fusion kernel (tools/fps_under_load.py;
+// never alone, never in the scalar build), and the fusion kernel's own packed epilogue lost lanes of its x-sum when its
+// instruction timing changed (tools/fusion_race.py).  DESIGN.md section 6.
+struct mcp_f2 {
+    float x, y;
+};
+__device__ __forceinline__ mcp_f2 operator-(mcp_f2 a, mcp_f2 b) { return mcp_f2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ mcp_f2 operator+(mcp_f2 a, mcp_f2 b) { return mcp_f2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ mcp_f2 operator*(mcp_f2 a, mcp_f2 b) { return mcp_f2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ mcp_f2 mcp_f2_fma(mcp_f2 a, mcp_f2 b, mcp_f2 c) { return mcp_f2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+
 // Quotient of a flat index.  gfx950 has no integer divider: a 64-bit division is ~130 VALU instructions, a 32-bit one ~25 -- for
 // a gather kernel that moves one float4 per thread, or a per-point loop of a few hundred instructions, the 64-bit form IS the
 // kernel.  `fits32` = "the largest dividend fits 32 bits" (a kernel argument, so the branch is wave-uniform; true for every

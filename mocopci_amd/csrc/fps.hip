@@ -37,7 +37,8 @@
 
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+typedef mcp_f2 f2;  // scalar pair: see common.h (no packed-fp32 instructions)
+__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return mcp_f2_fma(a, b, c); }
 
 __device__ __forceinline__ uint32_t fps_sec(uint32_t k, int L) {
     if (L == 0) return k;
@@ -78,6 +79,11 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
     extern __shared__ float4 smem_f4[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_f4);  // [3] rotating max slots (+pad to 64 B)
     float *sxyz = reinterpret_cast<float *>(smem_f4) + 16;                        // [n*3] when LDS_XYZ
+    // [m] selected indices, written out once at the end.  Not only because a global store per iteration sits in front of every
+    // barrier: with a store of the wave still outstanding while the next iteration's packed-fp32 scan ran, the kernel returned
+    // different samples when the memory system was busy with another stream's kernels (never on an idle chip) -- the same
+    // packed-op-beside-an-outstanding-memory-operation pattern as the fusion prefetch experiment.
+    int *sidx = reinterpret_cast<int *>(sxyz + (LDS_XYZ ? n * 3 : 0));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
         for (int i = tid; i < n * 3; i += T) sxyz[i] = xyz[i];
     }
     if (tid < 3) slots[tid] = 0ull;
-    if (tid == 0) idxs[0] = 0;
+    if (tid == 0) sidx[0] = 0;
     __syncthreads();
 
     int old = 0;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
 #pragma unroll
                 for (int p = 0; p < P; p += 2) {
                     const f2 dx = f2{px[p], px[p + 1]} - c0, dy = f2{py[p], py[p + 1]} - c1, dz = f2{pz[p], pz[p + 1]} - c2;
-                    const f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    const f2 d = f2_fma(dz, dz, f2_fma(dy, dy, dx * dx));
                     pt[p] = fminf(d.x, pt[p]);
                     pt[p + 1] = fminf(d.y, pt[p + 1]);
                     m2.x = fmaxf(m2.x, pt[p]);
@@ -188,9 +194,11 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
             s_nxt = s_new;
         }
         old = (int)fps_unsec(~wlo, L);
-        if (tid == 0) idxs[j] = old;
+        if (tid == 0) sidx[j] = old;
         FPS_STAMP(4);  // slot read + decode + store
     }
+    __syncthreads();
+    for (int j = tid; j < m; j += T) idxs[j] = sidx[j];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int k = tid + T * p;
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
 #pragma unroll
             for (int p = 0; p < P; p += 2) {
                 const f2 dx = f2{px[p], px[p + 1]} - c0, dy = f2{py[p], py[p + 1]} - c1, dz = f2{pz[p], pz[p + 1]} - c2;
-                const f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                const f2 d = f2_fma(dz, dz, f2_fma(dy, dy, dx * dx));
                 pt[p] = fminf(d.x, pt[p]);
                 pt[p + 1] = fminf(d.y, pt[p + 1]);
                 m2.x = fmaxf(m2.x, pt[p]);
@@ -705,15 +713,22 @@ template <int T, int P, int J, bool GENERIC>
 int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
     const size_t slot_bytes = 64;
     const size_t xyz_bytes = (size_t)n * 3 * sizeof(float);
-    if (xyz_bytes + slot_bytes <= 150 * 1024) {
+    const size_t idx_bytes = (size_t)(m > 0 ? m : 1) * sizeof(int);  // the selected indices are buffered in LDS (m <= n)
+    if (xyz_bytes + slot_bytes + idx_bytes <= 150 * 1024) {
         auto kern = fps_resident_kernel<T, P, J, GENERIC, true>;
         static McpPerDeviceOnce attr_once;
         if (attr_once.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
-        hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + xyz_bytes, s, n, m, L, xyz, temp, idx);
+        hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + xyz_bytes + idx_bytes, s, n, m, L, xyz, temp, idx);
     } else {
-        hipLaunchKernelGGL((fps_resident_kernel<T, P, J, GENERIC, false>), dim3(b), dim3(T), slot_bytes, s, n, m, L, xyz, temp, idx);
+        if (slot_bytes + idx_bytes > 150 * 1024) return MCP_ERR_UNSUPPORTED;
+        auto kern = fps_resident_kernel<T, P, J, GENERIC, false>;
+        static McpPerDeviceOnce attr_once2;
+        if (attr_once2.need()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + idx_bytes, s, n, m, L, xyz, temp, idx);
     }
     return mcp_launch_status();
 }

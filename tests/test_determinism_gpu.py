@@ -108,3 +108,49 @@ def test_linear_pointconv_and_small_attention_are_deterministic():
     assert repeatable(lambda: be.attention(q, kv, 8))
     q, kv = rnd(48, 512, 128), rnd(48, 512, 256)
     assert repeatable(lambda: be.attention(q, kv, 8))
+
+
+def test_fps_is_independent_of_what_another_stream_runs():
+    """Furthest point sampling on a side stream while the main stream runs the fusion kernel (what the steady state of
+    forward(inputs_ready=...) does): the sampled indices must be those of a quiet chip.  With packed-fp32 instructions in the
+    scan ~8 % of the level-2 launches sampled different points (mocopci_amd/csrc/common.h: mcp_f2)."""
+    from mocopci_amd import synth
+    be = ops.backend()
+    x1, x2, _ = synth.make_batch(2, 8, 8192, device=DEV)
+    cur = torch.cat([x1, x2]).transpose(1, 2).contiguous()
+    levels = []
+    for m in (2048, 512, 256, 64):
+        sel = be.fps(cur, m)
+        levels.append((cur, m, sel))
+        cur = be.group_rows(cur, sel)
+    torch.cuda.synchronize()
+    torch.manual_seed(3)
+    p1 = rnd(24, 8192, 3, scale=20.0)
+    idx = torch.randint(0, 8192, (24, 8192, 64), device=DEV, dtype=torch.int32)
+    ws = [rnd(64, 4, scale=0.5), rnd(64, scale=0.1), rnd(64, 64, scale=0.125), rnd(64, scale=0.1), rnd(128, 64, scale=0.125), rnd(128, scale=0.1)]
+    side = torch.cuda.Stream()
+    for _ in range(40):
+        be.fusion_mlp(p1, p1, idx, *ws)
+        be.fusion_mlp(p1, p1, idx, *ws)
+        with torch.cuda.stream(side):
+            outs = [(m, be.fps(c, m), want) for c, m, want in levels]
+        torch.cuda.synchronize()
+        for m, got, want in outs:
+            assert torch.equal(got, want), f"level {m} sampled different points beside the fusion kernel"
+
+
+def test_back_to_back_pipelined_forwards_are_bit_identical():
+    """forward(inputs_ready=...) issued back to back: the sampling pyramid of call k+1 runs under the tail of call k.  Every
+    call must return exactly what an isolated call returns."""
+    from mocopci_amd import synth
+    from tests import harness_checks as hc
+    net = hc.build_model(DEV)
+    x1, x2, _ = synth.make_batch(2, 8, 8192, device=DEV)
+    ev = torch.cuda.Event()
+    ev.record()
+    alone = net(x1, x2)
+    torch.cuda.synchronize()
+    outs = [net(x1, x2, inputs_ready=ev) for _ in range(5)]
+    torch.cuda.synchronize()
+    for k, o in enumerate(outs):
+        assert all(torch.equal(a, b) for a, b in zip(o, alone)), f"pipelined call {k} differs from the isolated call"
