@@ -167,6 +167,13 @@ class HipBackend:
         scope[key] = (xyz, cloud, cur, done)
         return cloud
 
+    def prebuild_cloud(self, xyz):
+        """Build the Morton-sorted form of a cloud now, on the current stream, when a later search of this cloud_scope will want
+        it (a cloud large enough for the pruned search): lets a caller put the build on a side stream, off the critical path.
+        No-op outside a scope or for small clouds."""
+        if getattr(self._tls, "scope", None) is not None and self.PRUNE_MIN_REFS <= xyz.shape[1] <= 65536:
+            self._sorted_cloud(xyz.detach())
+
     def knn(self, query, ref, k, mode=MCP_DIST_EXPANSION, return_dist=False):
         """knn_point(k, ref, query) (mocopci.py:1158-1169): (B,Q,3),(B,N,3) -> (B,Q,k) int32,
         ascending by (distance, index)."""

@@ -10,6 +10,9 @@ from . import pointset as orc
 class OracleBackend:
     name = "oracle-cpu"
 
+    def prebuild_cloud(self, xyz):
+        pass
+
     def cloud_scope(self):
         import contextlib
         return contextlib.nullcontext()
