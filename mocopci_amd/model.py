@@ -54,7 +54,6 @@ class Early:
 
     def __init__(self, model, device):
         self.model, self.device = model, device
-        self.main = torch.cuda.current_stream(device) if device.type == "cuda" else None
         self.items = {}
 
     def launch(self, key, fn, lane=1):
@@ -63,19 +62,22 @@ class Early:
         if aux is None:
             self.items[key] = (fn(), None)
             return
-        aux.wait_stream(self.main)  # inputs were produced on the main stream
+        aux.wait_stream(torch.cuda.current_stream(self.device))  # inputs were produced on the launching stream
         with torch.cuda.stream(aux):
             res = fn()
             ev = torch.cuda.Event()
             ev.record(aux)
-        for t in (res if isinstance(res, (tuple, list)) else (res,)):
-            t.record_stream(self.main)
         self.items[key] = (res, ev)
 
     def get(self, key):
+        """The READING stream (whichever is current: the encoder may run on a stream of its own, the decoder reads) waits for the
+        result and is recorded as a user of its memory."""
         res, ev = self.items[key]
         if ev is not None:
-            self.main.wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in (res if isinstance(res, (tuple, list)) else (res,)):
+                t.record_stream(cur)
         return res
 
 
