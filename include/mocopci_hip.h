@@ -189,11 +189,12 @@ int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int
  * neighbours of LeakyReLU(wmlp . LeakyReLU(points2[idx] + points1 + wpos.(xyz2[idx]-xyz1) + bpos) + bmlp).
  * The layer's weights -- wpos (D,3), bpos (D) = the Conv2d 3->D; wmlp (D,D), bmlp (D) = the single Conv2d D->D of
  * the mlp list (every layer MoCoPCI builds has exactly one) -- are packed ONCE per layer by mcp_cross_pack into
- * the MFMA-operand image (mcp_cross_packed_floats(D) floats, 16-byte aligned, caller-owned).  D in {64,128}, k = 32.  Neighbour lists: idx (B,N1,32), or with idx2 != NULL
+ * the MFMA-operand image (mcp_cross_packed_floats(D) floats, 16-byte aligned, caller-owned).  D in {64,128,256}, k = 32.  Neighbour lists: idx (B,N1,32), or with idx2 != NULL
  * the 16 + 16 halves as two (B,N1,16) lists (feature-space neighbours, then coordinate-space neighbours).  bmap != NULL (B int32):
  * the batch replicates / selects a smaller one -- element bb of the tensors flagged in `shared` (1 points1, 2 points2, 4 the
  * first index list) is read from element bmap[bb] of the unreplicated tensor (Multiframe_Attention's three flow iterations share
- * their features, mocopci.py:191-197); xyz1, xyz2 and idx2 are per element. */
+ * their features, mocopci.py:191-197); xyz1, xyz2 and idx2 are per element.  The map is kept in LDS: b <= 1024 when one is passed
+ * (MCP_ERR_UNSUPPORTED beyond). */
 int mcp_cross_packed_floats(int d);
 int mcp_cross_pack(int d, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, float *packed,
                    mcp_stream_t stream);
@@ -243,7 +244,7 @@ int mcp_linear(long long rows, int n, int nseg, const float *const *x, const int
  * trans_block / trans_block_2 -> mapping_xyz, :566-567 / :510-511):
  *     out[r, 0:cout] = (res ? res[r] : 0) + b2 + W2 . act(W1 . x[r] + b1),   act(v) = v > 0 ? v : slope * v   (PReLU with one slope)
  * x (rows, cin) with row stride x_stride floats (16-byte aligned rows), W1 (hidden, cin), W2 (cout, hidden); the (rows, hidden)
- * activation is never written.  Supported (the shapes where it beats the BLAS chain): cin 64 (cout <= 64), cin 128 (cout <= 32);
+ * activation is never written.  Supported (the shapes where it beats the BLAS chain): cin 64 (cout <= 64), cin 128 (cout <= 32 or 97..128);
  * hidden a multiple of 32.  The weights are prepared once by mcp_mlp2_pack into mcp_mlp2_packed_floats(cin, hidden, cout) caller-owned
  * floats (0 = unsupported shape).  Depthwise k=1 convolutions and eval-mode BatchNorms around the first layer are affine and are
  * folded into (W1, b1) by the caller. */
