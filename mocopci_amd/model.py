@@ -690,7 +690,12 @@ class MoCoPCI(nn.Module):
         def fold():
             w3 = torch.cat([self.W(prefix + w) for w in (".w_qs", ".w_ks", ".w_vs")], dim=0)
             return (w3 @ self.W(prefix + ".fc1")).contiguous(), (w3 @ self.Bv(prefix + ".fc1")).contiguous()
-        return F.linear(feats, *self.derived(("qkv_fold", prefix), fold))
+        w, b = self.derived(("qkv_fold", prefix), fold)
+        be = ops.backend()
+        if be.linear_supported(feats, w.shape[0]):  # tall inputs: the fused per-point Linear (67 vs 86 us at 196608 rows)
+            packed = None if self._live is not None else self.derived(("qkv_pack", be.name, prefix), lambda: be.linear_pack(w, b, [feats.shape[-1]]))
+            return be.linear(feats, w, b, 1.0, None, packed=packed)
+        return F.linear(feats, w, b)
 
     def transformer_block(self, prefix, feats, xyz, k=16, qkv=None):
         """TransformerBlock.forward (pointT_layer2.py:58-77): vector attention over the 16 nearest
