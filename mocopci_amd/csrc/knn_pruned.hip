@@ -99,6 +99,10 @@ __global__ __launch_bounds__(64) void tile_box_kernel(int n, int tiles, const fl
 // held in registers (IPT per thread): stable, so points of one cell stay in index order -- the same permutation as
 // sorting (code << 32 | index).
 constexpr int BT = 1024;
+#ifndef MCP_CLOUD_CELL_BITS
+#define MCP_CLOUD_CELL_BITS 7
+#endif
+constexpr int CELL_BITS = MCP_CLOUD_CELL_BITS;
 template <int IPT>
 struct CloudSort {
     using Sort = rocprim::block_radix_sort<uint32_t, BT, IPT, uint32_t>;
@@ -152,13 +156,15 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int tiles, const
 #pragma unroll
     for (int u = 0; u < IPT; ++u) {
         const int i = tid * IPT + u;
-        uint32_t k = 0x40000000u;
+        // CELL_BITS per axis: the order only steers the pruning (any order gives the same neighbours), and a <= 16384-point cloud
+        // has no use for 2^30 cells -- 7 bits per axis (cells of 1/128 of the extent) sort in 6 radix passes instead of 8
+        uint32_t k = 1u << (3 * CELL_BITS);
         if (i < n) {
             uint32_t c[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 float t = ext > 0.f ? (xyz[(size_t)i * 3 + a] - bbox[a]) / ext : 0.f;
-                t = fminf(fmaxf(t * 1024.f, 0.f), 1023.f);
+                t = fminf(fmaxf(t * (float)(1 << CELL_BITS), 0.f), (float)((1 << CELL_BITS) - 1));
                 c[a] = (uint32_t)t;
             }
             k = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
@@ -166,8 +172,8 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int tiles, const
         keys[u] = k;
         vals[u] = (uint32_t)i;
     }
-    // 3. stable radix sort of the (code, index) pairs over bits 0..30
-    typename CloudSort<IPT>::Sort().sort(keys, vals, lds.sort, 0, 31);
+    // 3. stable radix sort of the (code, index) pairs over the code's bits (padding: the bit above them)
+    typename CloudSort<IPT>::Sort().sort(keys, vals, lds.sort, 0, 3 * CELL_BITS + 1);
     __syncthreads();
     // 4. permutation + sorted coordinates (sorted position s = tid*IPT + u)
 #pragma unroll
