@@ -168,10 +168,13 @@ class MoCoPCI(nn.Module):
         (ops.linear) where the backend takes the shape -- the tall per-point layers -- and the BLAS chain otherwise."""
         w, b = self.W(name), self.Bv(name)
         be = ops.backend()
-        if be.linear_supported(x, w.shape[0]):
-            packed = None if self._live is not None else self.derived(("lin_pack", be.name, name, x.shape[-1]),
-                                                                      lambda: be.linear_pack(w, b, [x.shape[-1]]))
-            return be.linear(x, w, b, slope, res, packed=packed)
+        pieces = isinstance(x, (tuple, list))  # the pieces of a concatenation along the channel axis: read in place by the kernel
+        if be.linear_supported(list(x) if pieces else x, w.shape[0]):
+            ks = [t.shape[-1] for t in x] if pieces else [x.shape[-1]]
+            packed = None if self._live is not None else self.derived(("lin_pack", be.name, name, tuple(ks)), lambda: be.linear_pack(w, b, ks))
+            return be.linear(list(x) if pieces else x, w, b, slope, res, packed=packed)
+        if pieces:
+            x = torch.cat(list(x), dim=-1)
         y = F.linear(x, w, b)
         if slope != 1.0:
             y = F.leaky_relu(y, slope)
@@ -615,8 +618,9 @@ class MoCoPCI(nn.Module):
 
     def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None, idx_c12=None):
         """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C)."""
-        c1 = torch.cat([f1_0, f1_1, f1_new], dim=-1)
-        c2 = torch.cat([f2_0, f2_1, f2_new], dim=-1)
+        c1, c2 = (f1_0, f1_1, f1_new), (f2_0, f2_1, f2_new)
+        if not ops.backend().linear_supported(list(c1), self.W(prefix + ".bid.cross_t11").shape[0]):
+            c1, c2 = torch.cat(c1, dim=-1), torch.cat(c2, dim=-1)  # library path: concatenate once, both projections read it
         b, fe = prefix + ".bid", prefix + ".fe"
         t11_1, t22_2 = self.lin(c1, b + ".cross_t11"), self.lin(c2, b + ".cross_t22")
         t11_2, t22_1 = self.lin(c2, b + ".cross_t11"), self.lin(c1, b + ".cross_t22")
