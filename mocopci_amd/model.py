@@ -679,7 +679,10 @@ class MoCoPCI(nn.Module):
         if self._mode is not None:  # net.train(): the block's BatchNorms see all five frames of a sample (mocopci.py:200-208)
             _, frames = self.multi_frame_att_full(prefix + ".cross_block", torch.stack([n1, *fes, n2], dim=1) + time_enc)
             return frames, n1, n2
-        x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                            # (B,3,N,C)
+        if self._live is None:  # one kernel: frame-major (R,B,N,C) read through a permuted view, written sample-major with the time codes
+            x = torch.add(fea.reshape(R, B2, *fea.shape[1:]).permute(1, 0, 2, 3), time_enc[:, 1:-1], out=fea.new_empty((B2, R, *fea.shape[1:])))
+        else:
+            x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                        # (B,3,N,C)
         # (the block's third output, downsample(x_f), is never read by MultiFrameEstimatier.forward in inference)
         if rows is not None:  # only some (sample, frame) flows are read downstream
             _, frames = self.multi_frame_att(prefix + ".cross_block", x, rows=rows, feats=False)
