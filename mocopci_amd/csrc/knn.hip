@@ -25,7 +25,7 @@ namespace {
 
 typedef mcp_key u64;  // 64-bit (distance, index) key, see topk.h
 #define KEY_INF MCP_KEY_INF
-constexpr int TILE = 256;  // reference points per LDS tile (per wave)
+constexpr int TILE = 64;   // reference points per LDS tile (per wave); small, so that the N = 256 .. 1024 searches can be split over 2-4 waves
 
 template <int MODE>
 __device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float qn, const float4 r) {
@@ -276,11 +276,13 @@ __global__ __launch_bounds__(256) void nn1_kernel(int n, int m, const float *__r
 }
 
 int pick_split(int b, int q, int n) {
-    // aim for >= 2 waves per SIMD (1024 SIMDs) while keeping at least two tiles per wave
+    // aim for >= 2 waves per SIMD (1024 SIMDs) while keeping at least two 64-reference tiles per wave.  (The rule used to keep
+    // two tiles per wave: the N = 512 / 1024 searches of the lower pyramid levels then ran 384-768 waves of 512 sequential
+    // references each on 1024 SIMDs, ~40 us launches on the critical path; splitting them took 0.3 ms off the step.)
     const long long waves = (long long)b * ((q + 63) / 64);
     const int ntiles = (n + TILE - 1) / TILE;
     int split = 1;
-    while (split < 4 && waves * split < 2048 && ntiles >= 4 * split) split *= 2;
+    while (split < 8 && waves * split < 2048 && ntiles >= 2 * split) split *= 2;
     return split;
 }
 
@@ -312,7 +314,8 @@ int dispatch_split(int split, int b, int q, int n, int k, const float *query, co
                    hipStream_t s) {
     if (split == 1) return dispatch_k<MODE, 1>(b, q, n, k, query, ref, idx, dist, s);
     if (split == 2) return dispatch_k<MODE, 2>(b, q, n, k, query, ref, idx, dist, s);
-    return dispatch_k<MODE, 4>(b, q, n, k, query, ref, idx, dist, s);
+    if (split == 4) return dispatch_k<MODE, 4>(b, q, n, k, query, ref, idx, dist, s);
+    return dispatch_k<MODE, 8>(b, q, n, k, query, ref, idx, dist, s);
 }
 
 }  // namespace
