@@ -20,7 +20,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int NW = 8, MAXSEG = 3;
+constexpr int MAXSEG = 3;
 
 struct Segs {
     const float *x[MAXSEG];
@@ -31,8 +31,8 @@ struct Segs {
 
 // floats of one chunk image: NT out tiles x 2 k-steps x 3 pieces x 64 lanes x uint4
 __host__ __device__ constexpr int chunk_floats(int nt) { return nt * 2 * 3 * 64 * 4; }
-// floats of one LDS stage buffer: kc chunks rounded up to whole passes of the 512-thread workgroup (uint4 per thread per pass)
-__host__ __device__ constexpr size_t stage_floats(int nt, int kc) { return (size_t)((kc * chunk_floats(nt) / 4 + 511) / 512) * 512 * 4; }
+// floats of one LDS stage buffer: kc chunks rounded up to whole passes of the workgroup of nw waves (uint4 per thread per pass)
+__host__ __device__ constexpr size_t stage_floats(int nt, int kc, int nw) { return (size_t)((kc * chunk_floats(nt) / 4 + 64 * nw - 1) / (64 * nw)) * (64 * nw) * 4; }
 
 // W (n x ktot) row-major; the K axis is the concatenation of the pieces, each padded to a multiple of 32 in the image
 __global__ __launch_bounds__(256) void linear_pack_kernel(int n, int ktot, int nseg, int k0, int k1, int k2, const float *__restrict__ w,
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(int n, int ktot, int n
 constexpr int XP = 36;              // floats per padded tile row (32 + 4: conflict-free for both access patterns)
 constexpr int XT = 32 * XP;         // one 32 x 32 tile
 
-template <int NT, int KC>
+template <int NT, int KC, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int n, Segs sg, int nseg, int total_chunks, float slope,
                                                              const float *__restrict__ packed, const float *__restrict__ res, int rs_,
                                                              float *__restrict__ out, int os_) {
@@ -229,12 +229,12 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int 
     }
 }
 
-template <int NT, int KC>
+template <int NT, int KC, int NW>
 int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
                      float *out, int os_, hipStream_t s) {
-    auto kern = linear_kernel<NT, KC>;
-    const size_t lds = (2 * stage_floats(NT, KC) + (size_t)NW * XT) * sizeof(float);
-    static_assert((2 * stage_floats(NT, KC) + (size_t)NW * XT) * sizeof(float) <= 160 * 1024, "LDS budget");
+    auto kern = linear_kernel<NT, KC, NW>;
+    const size_t lds = (2 * stage_floats(NT, KC, NW) + (size_t)NW * XT) * sizeof(float);
+    static_assert((2 * stage_floats(NT, KC, NW) + (size_t)NW * XT) * sizeof(float) <= 160 * 1024, "LDS budget");
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -244,14 +244,22 @@ int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_
     return mcp_launch_status();
 }
 
-// stage depth by shape: long K gets KC chunks per barrier (two stages of 12 KB per chunk per 32 outputs beside the 36 KB of tiles)
+// stage depth by shape: long K gets KC chunks per barrier (two stages of 12 KB per chunk per 32 outputs beside the tiles).
+// Workgroup size by rows: 8 waves (256 rows) share one weight stream where there are rows enough to fill the chip several times
+// over; below that 4-wave workgroups (128 rows) -- 32768 rows are 128 eight-wave workgroups on 256 CUs.
+template <int NT, int NW>
+int launch_linear_nw(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
+                     float *out, int os_, hipStream_t s) {
+    constexpr int KC = NT <= 2 ? 4 : NT <= 4 ? 2 : 1;
+    if (KC > 1 && total_chunks >= 2 * KC)
+        return launch_linear_kc<NT, KC, NW>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+    return launch_linear_kc<NT, 1, NW>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+}
 template <int NT>
 int launch_linear(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
                   float *out, int os_, hipStream_t s) {
-    constexpr int KC = NT <= 2 ? 4 : NT <= 4 ? 2 : 1;
-    if (KC > 1 && total_chunks >= 2 * KC)
-        return launch_linear_kc<NT, KC>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
-    return launch_linear_kc<NT, 1>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+    if (rows >= 131072 || NT > 4) return launch_linear_nw<NT, 8>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+    return launch_linear_nw<NT, 4>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
 }
 
 int count_chunks(int nseg, const int *k) {
