@@ -107,7 +107,7 @@ def log_call_shapes(be, step):
     3-NN searches inside interp3 / interp3_search reach the timer through be.knn, so only be.knn records them; the fused
     small-level mcp_interp3 call (its own KNN launch inside the library) records here."""
     calls = {k: [] for k in FAMILIES}
-    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "ptblock_attention", "mlp2", "linear")
+    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "ptblock_attention", "mlp2", "linear", "linear_narrow")
     orig = {n: getattr(be, n) for n in names}
 
     def wrap(name, rec):
@@ -132,6 +132,7 @@ def log_call_shapes(be, step):
     be.linear = wrap("linear", lambda xs, w, *a, **k: calls["linear"].append(((xs[0] if isinstance(xs, (tuple, list)) else xs).numel()
                                                                                // (xs[0] if isinstance(xs, (tuple, list)) else xs).shape[-1],
                                                                                w.shape[1], w.shape[0])))
+    be.linear_narrow = wrap("linear_narrow", lambda x, w, *a, **k: calls["linear"].append((x.numel() // x.shape[-1], w.shape[1], w.shape[0])))
     be.mlp2 = wrap("mlp2", lambda x, w1, b1, w2, *a, **k: calls["mlp"].append((x.numel() // x.shape[-1], w1.shape[1], w1.shape[0], w2.shape[0])))
     try:
         step()

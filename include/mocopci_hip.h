@@ -236,6 +236,11 @@ int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *d
  * the concatenated K axis; n <= 128, or 129..192, or 193..256.  mcp_linear_pack prepares (W, b) once into
  * mcp_linear_packed_floats(n, nseg, k_seg) caller-owned floats (0 = unsupported shape); b may be NULL. */
 int mcp_linear_packed_floats(int n, int nseg, const int *k_seg);
+/* Narrow-output Linear with the activation on its input: out[r, 0:n] = b + W . act(x[r]), act(v) = v > 0 ? v : in_slope v; n <= 4,
+ * k in {256, 512, 1024}; W (n, k) row-major, x rows 16-byte aligned with stride x_stride floats.  The tail of Mlp_T where only the
+ * flow is read (PReLU, then fc2 and mapping_xyz folded into one 4C -> 3 map, mocopci.py:1561-1565 with :566-567 / :510-511). */
+int mcp_linear_narrow(long long rows, int k, int n, const float *x, int x_stride, const float *w, const float *b, float in_slope,
+                      float *out, int out_stride, mcp_stream_t stream);
 int mcp_linear_pack(int n, int nseg, const int *k_seg, const float *w, const float *b, float *packed, mcp_stream_t stream);
 int mcp_linear(long long rows, int n, int nseg, const float *const *x, const int *x_stride, const int *k_seg, float slope,
                const float *packed, const float *res, int res_stride, float *out, int out_stride, mcp_stream_t stream);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "mcp_linear_packed_floats": [_i, _i, _p],
     "mcp_linear_pack": [_i, _i, _p, _p, _p, _p, _p],
     "mcp_linear": [ctypes.c_longlong, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _p],
+    "mcp_linear_narrow": [ctypes.c_longlong, _i, _i, _p, _i, _p, _p, _f, _p, _i, _p],
     "mcp_mlp2_packed_floats": [_i, _i, _i],
     "mcp_mlp2_pack": [_i, _i, _i, _p, _p, _p, _p, _p, _p],
     "mcp_mlp2": [ctypes.c_longlong, _i, _i, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p],

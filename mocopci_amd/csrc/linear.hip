@@ -262,6 +262,60 @@ int launch_linear(long long rows, int n, const Segs &sg, int nseg, int total_chu
     return launch_linear_nw<NT, 4>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
 }
 
+// Narrow-output Linear with the activation on its INPUT:  out[r, j] = b[j] + sum_k W[j, k] * act(x[r, k]),  j < n <= 4
+// (act(v) = v > 0 ? v : slope v).  The tail of Mlp_T where only a flow is read: PReLU, then the (4C -> 3) map that fc2 and
+// mapping_xyz fold into (mocopci.py:1561-1565, :566-567).  The library takes 67 us for 12288 x 1024 -> 3 (48 workgroups) after a
+// separate PReLU launch; this is a streaming reduction: a wave owns RW rows at a time, lanes run along K with float4 loads, W sits
+// in registers (K <= 1024: 3 x 16 floats per lane), three DPP wave sums per row.
+constexpr int NARROW_RW = 4;
+template <int KQ>  // float4 per lane per row: K = 256 * KQ
+__global__ __launch_bounds__(256) void linear_narrow_kernel(long long rows, int n, const float *__restrict__ x, int xs_, const float *__restrict__ w,
+                                                            const float *__restrict__ b, float slope, float *__restrict__ out, int os_) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int K = 256 * KQ;
+    float4 wr[4][KQ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < KQ; ++u) wr[j][u] = j < n ? *reinterpret_cast<const float4 *>(w + (size_t)j * K + 4 * (lane + 64 * u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long nblk = (rows + NARROW_RW - 1) / NARROW_RW;
+    for (long long blk = (long long)blockIdx.x * 4 + wave; blk < nblk; blk += (long long)gridDim.x * 4) {
+        float4 xv[NARROW_RW][KQ];
+#pragma unroll
+        for (int r = 0; r < NARROW_RW; ++r) {
+            const long long row = min(blk * NARROW_RW + r, rows - 1);
+#pragma unroll
+            for (int u = 0; u < KQ; ++u) xv[r][u] = *reinterpret_cast<const float4 *>(x + row * xs_ + 4 * (lane + 64 * u));
+        }
+#pragma unroll
+        for (int r = 0; r < NARROW_RW; ++r) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < KQ; ++u) {
+                const float v[4] = {xv[r][u].x, xv[r][u].y, xv[r][u].z, xv[r][u].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float a = v[c] > 0.f ? v[c] : v[c] * slope;
+                    const float wj[4] = {c == 0 ? wr[0][u].x : c == 1 ? wr[0][u].y : c == 2 ? wr[0][u].z : wr[0][u].w,
+                                         c == 0 ? wr[1][u].x : c == 1 ? wr[1][u].y : c == 2 ? wr[1][u].z : wr[1][u].w,
+                                         c == 0 ? wr[2][u].x : c == 1 ? wr[2][u].y : c == 2 ? wr[2][u].z : wr[2][u].w,
+                                         c == 0 ? wr[3][u].x : c == 1 ? wr[3][u].y : c == 2 ? wr[3][u].z : wr[3][u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(wj[j], a, acc[j]);
+                }
+            }
+            const long long row = blk * NARROW_RW + r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sum = acc[j];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                if (lane == 0 && j < n && row < rows) out[row * os_ + j] = sum + (b ? b[j] : 0.f);
+            }
+        }
+    }
+}
+
 int count_chunks(int nseg, const int *k) {
     int c = 0;
     for (int i = 0; i < nseg; ++i) c += (k[i] + 31) / 32;
@@ -269,6 +323,22 @@ int count_chunks(int nseg, const int *k) {
 }
 
 }  // namespace
+
+MCP_EXPORT int mcp_linear_narrow(long long rows, int k, int n, const float *x, int x_stride, const float *w, const float *b, float in_slope,
+                                 float *out, int out_stride, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(rows > 0 && x && w && out);
+    if (n < 1 || n > 4 || (k != 256 && k != 512 && k != 1024)) return MCP_ERR_UNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)w)) & 15) || (x_stride & 3) || x_stride < k || out_stride < n) return MCP_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long nblk = (rows + NARROW_RW - 1) / NARROW_RW;
+    const unsigned grid = (unsigned)min((nblk + 3) / 4, 4096LL);
+    mcp_prof_begin(MCP_KERNEL_LINEAR, s);
+    if (k == 256) hipLaunchKernelGGL(linear_narrow_kernel<1>, dim3(grid), dim3(256), 0, s, rows, n, x, x_stride, w, b, in_slope, out, out_stride);
+    else if (k == 512) hipLaunchKernelGGL(linear_narrow_kernel<2>, dim3(grid), dim3(256), 0, s, rows, n, x, x_stride, w, b, in_slope, out, out_stride);
+    else hipLaunchKernelGGL(linear_narrow_kernel<4>, dim3(grid), dim3(256), 0, s, rows, n, x, x_stride, w, b, in_slope, out, out_stride);
+    mcp_prof_end(MCP_KERNEL_LINEAR, s);
+    return mcp_launch_status();
+}
 
 MCP_EXPORT int mcp_linear_packed_floats(int n, int nseg, const int *k_seg) {
     if (n <= 0 || n > 256 || nseg < 1 || nseg > MAXSEG || !k_seg) return 0;

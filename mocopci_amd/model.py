@@ -514,6 +514,10 @@ class MoCoPCI(nn.Module):
         w1, b1, w2, b2 = self.derived(("mlp_t", prefix, tail, bn), fold)
         live = self._live is not None
         if drop > 0.0 or not be.mlp2_supported(w1.shape[1], w1.shape[0], w2.shape[0]):  # dropout, or widths the kernel is not built for
+            if drop <= 0.0 and res is None and be.linear_narrow_supported(x.numel() // x.shape[-1], w1.shape[0], w2.shape[0]):
+                # flow tail at widths mlp2 is not built for (C = 256): library GEMM, then PReLU + the (4C -> 3) map as one kernel
+                slope = P[prefix + ".act.weight"] if live else self.derived(("slope", prefix), lambda: float(P[prefix + ".act.weight"]))
+                return be.linear_narrow(F.linear(x, w1, b1), w2, b2, slope)
             hid = self.dropout(F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"]), drop)
             out = self.dropout(F.linear(hid, w2, b2), drop)
             return out if res is None else out + res

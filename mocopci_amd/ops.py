@@ -422,6 +422,7 @@ class HipBackend:
         return _lib.load().mcp_linear_packed_floats(n, len(ps), ks) != 0
 
     _NO_LINEAR = os.environ.get("MCP_NO_LINEAR", "0") == "1"
+    _NO_NARROW = os.environ.get("MCP_NO_NARROW", "0") == "1"
     _LIN_MIN_ROWS = int(os.environ.get("MCP_LINEAR_MIN_ROWS", "16384"))
     _LIN_MAX_K = int(os.environ.get("MCP_LINEAR_MAX_K", "320"))
     _LIN_MAX_N = int(os.environ.get("MCP_LINEAR_MAX_N", "192"))
@@ -458,6 +459,24 @@ class HipBackend:
         if isinstance(xs, (tuple, list)) and grad.wants_grad(*xs, w, b, res):
             return grad.linear_twin(xs, w, b, slope, res)  # training: plain autograd over the concatenation
         return grad.run(fused, grad.linear_twin, xs, w, b, slope, res)
+
+    def linear_narrow_supported(self, rows, k, n):
+        """act-then-Linear with at most 4 outputs over K in {256, 512, 1024} (see linear_narrow)."""
+        return not (self._NO_LINEAR or self._NO_NARROW) and n <= 4 and k in (256, 512, 1024) and rows >= 1024
+
+    def linear_narrow(self, x, w, b, in_slope):
+        """b + W . act(x) over the last axis, act(v) = v > 0 ? v : in_slope v, W (n <= 4, K): the flow tail of Mlp_T (PReLU, then
+        fc2 and mapping_xyz as one 4C -> 3 map) as one streaming kernel instead of an activation launch and a 3-column GEMM."""
+        def fused(x_, w_, b_, slope_):
+            x2 = x_.reshape(-1, x_.shape[-1])
+            x2 = x2 if x2.stride(1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 else x2.contiguous()
+            rows, k, n = x2.shape[0], x2.shape[1], w_.shape[0]
+            out = torch.empty((rows, n), dtype=torch.float32, device=x_.device)
+            _call("mcp_linear_narrow", x_, rows, k, n, _lib.fptr(x2) if x2.is_contiguous() else x2.data_ptr(), x2.stride(0), _lib.fptr(w_.contiguous()),
+                  None if b_ is None else _lib.fptr(b_.contiguous()), float(slope_), _lib.fptr(out), n)
+            return out.reshape(*x_.shape[:-1], n)
+        twin = lambda x_, w_, b_, slope_: torch.nn.functional.linear(torch.where(x_ > 0, x_, x_ * slope_), w_, b_)
+        return grad.run(fused, twin, x, w, b, in_slope)
 
     def mlp2_pack(self, w1, b1, w2, b2):
         """Operand image of one two-layer MLP for mlp2 (split once; do this once per block)."""

@@ -612,3 +612,21 @@ def test_cross_volume_batch_map_equals_replicated_inputs():
     got4 = be.cross_volume(xyz1.to(DEV), xyz2.to(DEV), p1[m].contiguous().to(DEV), p2[m].contiguous().to(DEV), (idx_c.to(DEV), idx_p.to(DEV)),
                            packed, bmap=m.int().to(DEV), shared=4)
     assert torch.equal(got4, want)
+
+
+@pytest.mark.parametrize("rows,k,n", [(12288, 1024, 3), (4099, 256, 4), (2048, 512, 1)])
+def test_linear_narrow_matches_torch(rows, k, n):
+    """PReLU followed by a (K -> n <= 4) Linear as one streaming kernel (the folded flow tail of Mlp_T, mocopci.py:1561-1565 with
+    :566-567): against the oracle backend's two-step form; K-long fp32 sums in a different order, hence the tolerance."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(rows + k)
+    wide = torch.randn(rows, k + 8, generator=g)
+    x = wide[:, 4:4 + k]                                            # a column slice: rows 16-byte aligned, stride k + 8
+    w, b = torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g) * 0.1
+    want = OracleBackend().linear_narrow(x, w, b, 0.25)
+    be = ops.backend()
+    assert be.linear_narrow_supported(rows, k, n) and not be.linear_narrow_supported(rows, 300, n) and not be.linear_narrow_supported(rows, k, 5)
+    got = be.linear_narrow(wide.to(DEV)[:, 4:4 + k], w.to(DEV), b.to(DEV), 0.25)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
+    got2 = be.linear_narrow(x.contiguous().to(DEV).reshape(1, rows, k), w.to(DEV), None, 0.0)
+    torch.testing.assert_close(got2.cpu()[0], torch.nn.functional.linear(torch.relu(x), w), rtol=2e-5, atol=2e-5)

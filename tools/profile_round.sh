@@ -21,4 +21,5 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_
 echo "sq done"
 python3 tools/pmc_counters.py "$out/pmc.json" $(find "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" -name '*counter_collection.csv') | tee "$out/pmc_summary.txt"
 # the raw per-dispatch CSVs are large: keep only the merged JSON and the stats
+python3 tools/step_timeline.py "$db" > "$out/step_timeline.txt" 2>&1 || true
 rm -rf "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" "$out/trace"
