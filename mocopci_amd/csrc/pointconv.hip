@@ -16,8 +16,9 @@
 
 namespace {
 
-constexpr int K = 32, WN = 8, PPB = 8, THREADS = PPB * K;  // 256 threads
+constexpr int K = 32, WN = 8, PPB = 8;  // phase 1 uses PPB * K = 256 threads; phase 2 all THREADS of the workgroup
 
+template <int THREADS>
 __global__ __launch_bounds__(THREADS) void pointconv_agg_kernel(long long total, int n, int s, int d, const float *__restrict__ s_xyz,
                                                                 const float *__restrict__ new_xyz, const float *__restrict__ s_points,
                                                                 const int *__restrict__ idx, const float *__restrict__ w0,
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(THREADS) void pointconv_agg_kernel(long long total,
         {   // ---- phase 1 ----
             const int pl = tid >> 5, k = tid & 31;
             const long long p = p0 + pl;
-            if (p < total) {
+            if (tid < PPB * K && p < total) {
                 const long long bb = mcp_div(p, s, f32);
                 const int id = idx[p * K + k];
                 const float *q = s_xyz + ((long long)bb * n + id) * 3;
@@ -133,8 +134,14 @@ MCP_EXPORT int mcp_pointconv_agg(int b, int n, int s, int d, int k, const float 
     // the two barriers per group overlap across resident workgroups (measured 1.10 -> 0.99 ms per step against a 4096-workgroup cap)
     const unsigned grid = (unsigned)min((total + PPB - 1) / PPB, 1LL << 20);
     mcp_prof_begin(MCP_KERNEL_POINTCONV, st);
-    hipLaunchKernelGGL(pointconv_agg_kernel, dim3(grid), dim3(THREADS), 0, st, total, n, s, d, s_xyz, new_xyz, s_points, idx, w0, b0, w1,
-                       b1, w2, b2, out);
+    // wide layers of the small levels (few workgroups, PPB * d channel sums each): 1024 threads walk the (point, channel) items of a
+    // group in 2-3 passes instead of 8-17 -- these launches are latency chains on an otherwise idle chip (49 -> 20 us at level 4, 31 -> 26 us at level 3; at d = 128 the wider group is slower: 29 -> 44 us)
+    if (d >= 256 && total <= 8192)
+        hipLaunchKernelGGL(pointconv_agg_kernel<1024>, dim3(grid), dim3(1024), 0, st, total, n, s, d, s_xyz, new_xyz, s_points, idx, w0, b0, w1,
+                           b1, w2, b2, out);
+    else
+        hipLaunchKernelGGL(pointconv_agg_kernel<256>, dim3(grid), dim3(256), 0, st, total, n, s, d, s_xyz, new_xyz, s_points, idx, w0, b0, w1,
+                           b1, w2, b2, out);
     mcp_prof_end(MCP_KERNEL_POINTCONV, st);
     return mcp_launch_status();
 }
