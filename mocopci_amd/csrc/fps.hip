@@ -136,12 +136,12 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
                 for (int p = 0; p < P; p += 2) {
                     const f2 dx = f2{px[p], px[p + 1]} - c0, dy = f2{py[p], py[p + 1]} - c1, dz = f2{pz[p], pz[p + 1]} - c2;
                     const f2 d = f2_fma(dz, dz, f2_fma(dy, dy, dx * dx));
-                    pt[p] = fminf(d.x, pt[p]);
-                    pt[p + 1] = fminf(d.y, pt[p + 1]);
-                    m2.x = fmaxf(m2.x, pt[p]);
-                    m2.y = fmaxf(m2.y, pt[p + 1]);
+                    pt[p] = mcp_min_raw(d.x, pt[p]);  // raw v_min / v_max: fminf / fmaxf first canonicalise an operand (an extra
+                    pt[p + 1] = mcp_min_raw(d.y, pt[p + 1]);  // instruction each); nothing here is ever NaN
+                    m2.x = mcp_max_raw(m2.x, pt[p]);
+                    m2.y = mcp_max_raw(m2.y, pt[p + 1]);
                 }
-                best = fmaxf(m2.x, m2.y);
+                best = mcp_max_raw(m2.x, m2.y);
             } else {
                 pt[0] = fminf(mcp_sqdist3(px[0], py[0], pz[0], x1, y1, z1), pt[0]);
                 best = fmaxf(-1.0f, pt[0]);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
         // exact lower bound of the lane's point distances (see the header comment); an all-padding lane has best = -1
         // (lo - c, c - hi) per axis as one packed add: (lo, -hi) + (-c, c)
         const f2 tx = bx + f2{-x1, x1}, ty = by + f2{-y1, y1}, tz = bz + f2{-z1, z1};
-        const float ex = fmaxf(fmaxf(tx.x, tx.y), 0.f), ey = fmaxf(fmaxf(ty.x, ty.y), 0.f), ez = fmaxf(fmaxf(tz.x, tz.y), 0.f);
+        const float ex = mcp_max3_raw(tx.x, tx.y, 0.f), ey = mcp_max3_raw(ty.x, ty.y, 0.f), ez = mcp_max3_raw(tz.x, tz.y, 0.f);
         const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
         const bool need = lb < best;
         FPS_STAMP(1);  // box test
@@ -362,12 +362,12 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
             for (int p = 0; p < P; p += 2) {
                 const f2 dx = f2{px[p], px[p + 1]} - c0, dy = f2{py[p], py[p + 1]} - c1, dz = f2{pz[p], pz[p + 1]} - c2;
                 const f2 d = f2_fma(dz, dz, f2_fma(dy, dy, dx * dx));
-                pt[p] = fminf(d.x, pt[p]);
-                pt[p + 1] = fminf(d.y, pt[p + 1]);
-                m2.x = fmaxf(m2.x, pt[p]);
-                m2.y = fmaxf(m2.y, pt[p + 1]);
+                pt[p] = mcp_min_raw(d.x, pt[p]);
+                pt[p + 1] = mcp_min_raw(d.y, pt[p + 1]);
+                m2.x = mcp_max_raw(m2.x, pt[p]);
+                m2.y = mcp_max_raw(m2.y, pt[p + 1]);
             }
-            best = fmaxf(m2.x, m2.y);
+            best = mcp_max_raw(m2.x, m2.y);
             const uint32_t hi = mcp_ord(best);
             const uint32_t whi = mcp_wave_max_u32(hi);
             uint32_t bsec = 0;  // points sit in curve order, so ties inside the lane compare the keys themselves
