@@ -115,6 +115,7 @@ class MoCoPCI(nn.Module):
     # ---- parameter access ---------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         self._cache = None
+        self.__dict__.pop("_state_tensors", None)  # .to() / .cuda() replace the parameter tensors
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -124,7 +125,10 @@ class MoCoPCI(nn.Module):
     def _state_version(self):
         """Changes whenever a parameter or buffer is written in place (optimizer.step(), a training forward's running statistics,
         copy_ / load) -- everything cached from them (folded BatchNorms, packed kernel operands) is then stale."""
-        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        ts = self.__dict__.get("_state_tensors")
+        if ts is None:  # the module tree is fixed after construction: walk it once (the walk costs more than a forward's other bookkeeping)
+            ts = self.__dict__["_state_tensors"] = [*self.parameters(), *self.buffers()]
+        return sum(t._version for t in ts)
 
     def _check_cache(self):
         """Once per forward: drop the inference cache if any parameter / buffer changed since it was built."""
