@@ -233,7 +233,7 @@ int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *d
  *     out[r, 0:n] = act( sum_i W_i . x_i[r] + b ) [+ res[r]],   act(v) = v > 0 ? v : slope * v   (slope 1: none, 0: ReLU, 0.1: LeakyReLU)
  * The input is given as nseg <= 3 pieces x[i] (rows, k_seg[i]) with row strides x_stride[i] (floats; 16-byte aligned rows,
  * k_seg[i] a multiple of 4): the pieces of what the reference concatenates, read in place.  W is (n, sum k_seg) row-major over
- * the concatenated K axis; n <= 128, or 129..192, or 193..256.  mcp_linear_pack prepares (W, b) once into
+ * the concatenated K axis; n <= 128, or 129..192, or 193..256, or wider in column blocks of 128 (n <= 2048, ceil(n/32) a multiple of 4).  mcp_linear_pack prepares (W, b) once into
  * mcp_linear_packed_floats(n, nseg, k_seg) caller-owned floats (0 = unsupported shape); b may be NULL. */
 int mcp_linear_packed_floats(int n, int nseg, const int *k_seg);
 /* Narrow-output Linear with the activation on its input: out[r, 0:n] = b + W . act(x[r]), act(v) = v > 0 ? v : in_slope v; n <= 4,

@@ -79,9 +79,12 @@ constexpr int XT = 32 * XP;         // one 32 x 32 tile
 
 template <int NT, int KC, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int n, Segs sg, int nseg, int total_chunks, float slope,
-                                                             const float *__restrict__ packed, const float *__restrict__ res, int rs_,
+                                                             const float *__restrict__ packed, int cf_total, const float *__restrict__ res, int rs_,
                                                              float *__restrict__ out, int os_) {
-    constexpr int CF = chunk_floats(NT), CH4 = CF / 4;  // floats / uint4 per chunk
+    // A workgroup owns NT output tiles (32 columns each) starting at tile tb = blockIdx.y * NT of the image's cf_total / 1536 tiles
+    // per chunk: outputs wider than 256 run as grid.y column blocks of 128, each re-reading (and re-splitting) its rows of x.
+    constexpr int CF = chunk_floats(NT), CH4 = CF / 4;  // floats / uint4 per chunk of this workgroup's NT tiles
+    const int tb = blockIdx.y * NT;
     constexpr int LOADS = (KC * CH4 + 64 * NW - 1) / (64 * NW);
     constexpr int SF = LOADS * 64 * NW * 4;  // floats per stage buffer: KC chunks, rounded up to whole passes of the workgroup
     extern __shared__ __attribute__((aligned(16))) float lds[];  // weights [2][SF] | tiles [NW][XT]
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int 
 
     f32x16 acc[NT];
     {
-        const float *bi = packed + (size_t)total_chunks * CF;
+        const float *bi = packed + (size_t)total_chunks * cf_total + tb * 32;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -106,9 +109,12 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int 
     u32x4 pre[LOADS];  // native vector type: an array of HIP's uint4 structs here ended up in scratch memory
 #define LIN_FETCH(st_)                                                                                          \
     {                                                                                                           \
-        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(packed + (size_t)(st_) * KC * CF);                  \
-        const int valid_ = min(KC, total_chunks - (st_) * KC) * CH4;                                            \
-        _Pragma("unroll") for (int u = 0; u < LOADS; ++u) pre[u] = src_[min(tid + u * 64 * NW, valid_ - 1)];    \
+        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(packed + (size_t)(st_) * KC * cf_total + tb * (CF / NT));  \
+        const int valid_ = min(KC, total_chunks - (st_) * KC);                                                  \
+        _Pragma("unroll") for (int u = 0; u < LOADS; ++u) {                                                     \
+            const int e_ = tid + u * 64 * NW, kk_ = min(e_ / CH4, valid_ - 1), w_ = e_ - (e_ / CH4) * CH4;      \
+            pre[u] = src_[(size_t)kk_ * (cf_total / 4) + w_];                                                   \
+        }                                                                                                       \
     }
 #define LIN_STASH(buf_)                                                                                         \
     {                                                                                                           \
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int 
             }
             *reinterpret_cast<float4 *>(tile + col * XP + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        const int ch = 32 * t + 4 * cq;
+        const int ch = 32 * (tb + t) + 4 * cq;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long long row = row0 + 8 * j + cr;
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int 
 
 template <int NT, int KC, int NW>
 int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
-                     float *out, int os_, hipStream_t s) {
+                     float *out, int os_, hipStream_t s, int col_blocks = 1) {
     auto kern = linear_kernel<NT, KC, NW>;
     const size_t lds = (2 * stage_floats(NT, KC, NW) + (size_t)NW * XT) * sizeof(float);
     static_assert((2 * stage_floats(NT, KC, NW) + (size_t)NW * XT) * sizeof(float) <= 160 * 1024, "LDS budget");
@@ -240,7 +246,8 @@ int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const long long groups = (rows + 32LL * NW - 1) / (32LL * NW);
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * NW), lds, s, rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups, col_blocks), dim3(64 * NW), lds, s, rows, n, sg, nseg, total_chunks, slope, packed,
+                       chunk_floats(NT * col_blocks), res, rs_, out, os_);
     return mcp_launch_status();
 }
 
@@ -249,11 +256,18 @@ int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_
 // over; below that 4-wave workgroups (128 rows) -- 32768 rows are 128 eight-wave workgroups on 256 CUs.
 template <int NT, int NW>
 int launch_linear_nw(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
-                     float *out, int os_, hipStream_t s) {
+                     float *out, int os_, hipStream_t s, int col_blocks = 1) {
     constexpr int KC = NT <= 2 ? 4 : NT <= 4 ? 2 : 1;
     if (KC > 1 && total_chunks >= 2 * KC)
-        return launch_linear_kc<NT, KC, NW>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
-    return launch_linear_kc<NT, 1, NW>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+        return launch_linear_kc<NT, KC, NW>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s, col_blocks);
+    return launch_linear_kc<NT, 1, NW>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s, col_blocks);
+}
+// outputs wider than 256 columns (a multiple of 128): column blocks of four tiles over grid.y
+int launch_linear_blocked(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res,
+                          int rs_, float *out, int os_, hipStream_t s) {
+    const int col_blocks = ((n + 31) / 32) / 4;
+    if (rows >= 131072) return launch_linear_nw<4, 8>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s, col_blocks);
+    return launch_linear_nw<4, 4>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s, col_blocks);
 }
 template <int NT>
 int launch_linear(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
@@ -341,11 +355,12 @@ MCP_EXPORT int mcp_linear_narrow(long long rows, int k, int n, const float *x, i
 }
 
 MCP_EXPORT int mcp_linear_packed_floats(int n, int nseg, const int *k_seg) {
-    if (n <= 0 || n > 256 || nseg < 1 || nseg > MAXSEG || !k_seg) return 0;
+    if (n <= 0 || n > 2048 || nseg < 1 || nseg > MAXSEG || !k_seg) return 0;
     for (int i = 0; i < nseg; ++i)
         if (k_seg[i] <= 0 || (k_seg[i] & 3)) return 0;
     const int nt = (n + 31) / 32;
-    if (nt == 5 || nt == 7) return 0;  // output widths the kernel is instantiated for: up to 128, 192, 256
+    if (nt == 5 || nt == 7) return 0;  // output widths the kernel is instantiated for: up to 128, 192, 256 ...
+    if (nt > 8 && (nt & 3)) return 0;  // ... and wider ones in column blocks of 128: a multiple of 128 (the last 31 columns may be missing)
     return count_chunks(nseg, k_seg) * chunk_floats(nt) + nt * 32;
 }
 
@@ -383,7 +398,7 @@ MCP_EXPORT int mcp_linear(long long rows, int n, int nseg, const float *const *x
         case 4: rc = launch_linear<4>(rows, n, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s); break;
         case 6: rc = launch_linear<6>(rows, n, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s); break;
         case 8: rc = launch_linear<8>(rows, n, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s); break;
-        default: rc = MCP_ERR_UNSUPPORTED;
+        default: rc = nt > 8 ? launch_linear_blocked(rows, n, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s) : MCP_ERR_UNSUPPORTED;
     }
     mcp_prof_end(MCP_KERNEL_LINEAR, s);
     return rc;

@@ -630,3 +630,18 @@ def test_linear_narrow_matches_torch(rows, k, n):
     torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
     got2 = be.linear_narrow(x.contiguous().to(DEV).reshape(1, rows, k), w.to(DEV), None, 0.0)
     torch.testing.assert_close(got2.cpu()[0], torch.nn.functional.linear(torch.relu(x), w), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows,k,n", [(4100, 256, 1536), (8192, 96, 500)])
+def test_linear_wide_outputs_run_as_column_blocks(rows, k, n):
+    """Outputs wider than 256 columns run as column blocks of 128 over grid.y (n <= 2048, ceil(n/32) a multiple of 4); the shape
+    policy leaves these to the library (only 10-15 % faster), the entry point takes them."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(rows + n)
+    x = torch.randn(rows, k, generator=g)
+    w, b = torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g) * 0.1
+    want = OracleBackend().linear(x, w, b, 0.25, None)
+    be = ops.backend()
+    assert not be.linear_supported(x.to(DEV), n)
+    got = be.linear(x.to(DEV), w.to(DEV), b.to(DEV), 0.25, None)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)

@@ -18,6 +18,8 @@ cases = [  # rows, piece widths, n, slope, residual
     (24576, (128,), 512, 0.25, False), (4096, (128,), 256, 1.0, False), (2048, (256,), 256, 1.0, False), (4096, (256, 256, 64), 256, 1.0, False),
     (32768, (64,), 128, 0.1, False), (16384, (64,), 64, 1.0, False), (4096, (2072,), 256, 0.1, False),
     (12288, (256,), 256, 1.0, False), (8192, (256,), 256, 1.0, False), (8192, (384,), 128, 1.0, False), (12288, (256,), 192, 1.0, False),
+    (8192, (256,), 1536, 1.0, False), (12288, (256,), 1024, 1.0, False), (8192, (256,), 768, 1.0, False), (12288, (256,), 1024, 0.25, False),
+    (24576, (128,), 512, 0.25, False), (2048, (256,), 512, 1.0, False), (4096, (256,), 512, 1.0, False), (49152, (64,), 256, 0.25, False),
 ]
 tot_l = tot_f = 0.0
 for rows, ks, n, slope, with_res in cases:
