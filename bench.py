@@ -329,8 +329,8 @@ def main():
                    "parallelism": f"sequence-sharded x{world}, final all_gather over RCCL" if world > 1 else "single GPU",
                    "weights": "deterministic by-name synthetic, eval mode",
                    "steps_in_flight": n_streams,
-                   "step_pipelining": "off (--serial)" if args.serial else "the furthest-point-sampling pyramid of step k+1 (input-only, side stream) "
-                                      "is issued behind the inputs' ready event and overlaps the tail of step k; all work of every step is inside the timed region",
+                   "step_pipelining": "off (--serial)" if args.serial else "the furthest-point-sampling pyramid and the level-0 self search of step k+1 (input-only, side streams) "
+                                      "are issued behind the inputs' ready event and overlap the tail of step k; all work of every step is inside the timed region",
                    "arithmetic": "fp32 values throughout; the fused MLP layers form each fp32 product from six bf16 MFMA partial products of an "
                                  "exact 3-way operand split (fp32 accumulation, ~4 ulp from the f32-input MFMA build)"},
         # Random (untrained) weights: the network's frames are nowhere near the scan, so these two are NOT quality numbers -- they only
