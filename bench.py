@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="do not pipeline the input-only sampling pyramid across consecutive steps")
+    ap.add_argument("--pipeline", choices=("prefetch", "event"), default="prefetch",
+                    help="prefetch: the next step's input-only work is issued under this step's decoder; event: issued at the next call (round 2)")
     ap.add_argument("--streams", type=int, default=1, help="steps in flight: consecutive steps issued round-robin on this many HIP streams "
                                                             "(measured: 2-3 give 0-10 %% depending on how the runtime maps the ~15 streams onto its 4 "
                                                             "hardware queues, not reproducibly; more hardware queues make it worse)")
@@ -258,23 +260,37 @@ def main():
     # round-robin on a few HIP streams, each with its own side streams.  Measured gain 0-10 %, not reproducible from run to run
     # (it depends on how the runtime maps the streams onto its hardware queues), hence not the default.
     n_streams = 1 if args.serial else max(1, args.streams)
+    # how consecutive steps overlap: "prefetch" (default), "event" (round 2: the input-only work of step k+1 is issued when step k+1
+    # is called, behind the inputs' event), "serial"
+    pipeline = "serial" if args.serial else ("event" if n_streams > 1 else args.pipeline)
     lanes = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream(dev)]
     for ln in lanes:
         ln.wait_stream(torch.cuda.current_stream(dev))
     counter = [0]
 
-    def step():
+    handle = [None]
+
+    def step(last=False):
+        """One forward.  Default pipelining: the input-only work of the NEXT step (sampling pyramid, level-0 self search) is issued
+        right after this step's encoder is enqueued (MoCoPCI.forward(then_prefetch=...)) and consumed by the next call.  `last`:
+        no next step -- nothing is prefetched, so a phase (warm-up, timed region, instrumented pass) issues exactly one pyramid
+        per step of its own: none is borrowed from the phase before, none is left over."""
         ln = lanes[counter[0] % n_streams]
         counter[0] += 1
         with torch.cuda.stream(ln):
-            out = net(x1, x2, inputs_ready=inputs_ready)   # 3 x (B,N,3)
+            if pipeline == "prefetch":
+                h = handle[0] if handle[0] is not None else net.prefetch(x1, x2, inputs_ready)
+                out = net(x1, x2, prefetched=h, then_prefetch=None if last else (x1, x2, inputs_ready))
+                handle[0] = net.take_prefetched()
+            else:
+                out = net(x1, x2, inputs_ready=inputs_ready)   # 3 x (B,N,3)
             return shard.gather_frames(out, world)  # (world*B,3,N,3) on every rank; no-op view for world == 1
 
-    for _ in range(args.warmup):
-        step()
-    calls = log_call_shapes(ops.backend(), step)
+    for i in range(args.warmup):
+        step(last=i == args.warmup - 1)
+    calls = log_call_shapes(ops.backend(), lambda: step(last=True))
     for _ in range(n_streams - 1):  # every lane has run at least once before the clock starts
-        step()
+        step(last=True)
 
     # Inside the timed region only the headline kernel is bracketed by hipEvents (two records per step).  Bracketing all nine
     # families (~45 launches per step) costs ~0.4 ms per step of stream time and serialises the steps in flight, so the other
@@ -284,8 +300,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frames = step()
+    for i in range(args.steps):
+        frames = step(last=i == args.steps - 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -293,8 +309,8 @@ def main():
     headline_timed = ops.prof_collect(HEADLINE)
     inst_steps = min(args.steps, 10)
     ops.prof_enable(FAMILIES)
-    for _ in range(inst_steps):
-        net(x1, x2, inputs_ready=inputs_ready)   # the same call as in the timed region (same kernels and shapes), one step in flight
+    for i in range(inst_steps):
+        step(last=i == inst_steps - 1)   # the same calls as in the timed region (same kernels and shapes)
     torch.cuda.synchronize()
     timed = {k: ops.prof_collect(k) for k in FAMILIES}
     ops.prof_enable(None)
@@ -329,8 +345,12 @@ def main():
                    "parallelism": f"sequence-sharded x{world}, final all_gather over RCCL" if world > 1 else "single GPU",
                    "weights": "deterministic by-name synthetic, eval mode",
                    "steps_in_flight": n_streams,
-                   "step_pipelining": "off (--serial)" if args.serial else "the furthest-point-sampling pyramid and the level-0 self search of step k+1 (input-only, side streams) "
-                                      "are issued behind the inputs' ready event and overlap the tail of step k; all work of every step is inside the timed region",
+                   "step_pipelining": {"serial": "off (--serial)",
+                                       "event": "the furthest-point-sampling pyramid and the level-0 self search of step k+1 (input-only, side streams) are issued "
+                                                "when step k+1 is called, behind the inputs' ready event, and overlap the tail of step k",
+                                       "prefetch": "the furthest-point-sampling pyramid and the level-0 self search of step k+1 (input-only, side streams) are issued "
+                                                   "right after step k's encoder is enqueued and run under step k's decoder; the first step of the timed region issues "
+                                                   "its own and the last step prefetches nothing: exactly `steps` pyramids run inside the timed region"}[pipeline],
                    "arithmetic": "fp32 values throughout; the fused MLP layers form each fp32 product from six bf16 MFMA partial products of an "
                                  "exact 3-way operand split (fp32 accumulation, ~4 ulp from the f32-input MFMA build)"},
         # Random (untrained) weights: the network's frames are nowhere near the scan, so these two are NOT quality numbers -- they only

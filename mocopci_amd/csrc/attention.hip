@@ -311,6 +311,7 @@ int launch_wide(int bf, int nq, int nk, int heads, const float *q, int qs, const
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(nq, 32 * WAVES), heads, bf), dim3(64 * WAVES), WideCfg<HD>::LDS_BYTES, s, nq, nk, q, qs, k, ks, v,
                        vs, sl2, out, os);

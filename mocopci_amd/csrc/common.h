@@ -68,17 +68,18 @@ void mcp_prof_end(int kernel_id, hipStream_t s);
     } while (0)
 
 // hipFuncSetAttribute applies to the CURRENT device, so "done" is remembered per device (one process may drive several
-// GPUs, e.g. under nn.DataParallel, train.py:73-80).  Racing threads at worst repeat the idempotent call.
+// GPUs, e.g. under nn.DataParallel, train.py:73-80).  need() only tests; the caller marks the device with done() AFTER the
+// attribute calls have returned, so a second thread on the same device either sees the bit (attribute set) or repeats the
+// idempotent calls itself -- it can never launch ahead of them.
 struct McpPerDeviceOnce {
-    unsigned long long done = 0ull;
-    bool need() {
+    unsigned long long bits = 0ull;
+    static unsigned long long device_bit() {
         int d = 0;
         (void)hipGetDevice(&d);
-        const unsigned long long bit = 1ull << (d & 63);
-        if (__atomic_load_n(&done, __ATOMIC_RELAXED) & bit) return false;
-        __atomic_fetch_or(&done, bit, __ATOMIC_RELAXED);
-        return true;
+        return 1ull << (d & 63);
     }
+    bool need() const { return !(__atomic_load_n(&bits, __ATOMIC_ACQUIRE) & device_bit()); }
+    void done() { __atomic_fetch_or(&bits, device_bit(), __ATOMIC_RELEASE); }
 };
 
 static inline int mcp_launch_status() {

@@ -292,6 +292,7 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
     }
     // at least 8 points per wave so the weight staging is amortised
     const long long want = (total + WAVES * 8 - 1) / (WAVES * 8);

@@ -696,6 +696,7 @@ int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, c
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
     }
     hipLaunchKernelGGL(fps_tiled_kernel, dim3(b), dim3(TL_T), lds, s, n, m, tiles, lds_idx, xyz, temp, idx, sx, st);
     return mcp_launch_status();
@@ -719,6 +720,7 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
         static McpPerDeviceOnce attr_once;
         if (attr_once.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_once.done();
         }
         hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + xyz_bytes + idx_bytes, s, n, m, L, xyz, temp, idx);
     } else {
@@ -727,6 +729,7 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
         static McpPerDeviceOnce attr_once2;
         if (attr_once2.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_once2.done();
         }
         hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + idx_bytes, s, n, m, L, xyz, temp, idx);
     }
@@ -749,6 +752,7 @@ int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, in
                                   160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
+        attr_once.done();
     }
     (void)L;  // n >= 1024: the reference block size is 1024 (asserted by the caller)
     if (lds_xyz) hipLaunchKernelGGL((fps_spatial_kernel<T, P, true>), dim3(b), dim3(T), lds, s, n, m, lds_idx, xyz, temp, idx);
@@ -756,9 +760,15 @@ int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, in
     return mcp_launch_status();
 }
 
+// tuning hooks exist only in -DMCP_AB builds; the shipped library reads no environment variable
 int env_int(const char *name, int dflt) {
+#ifdef MCP_AB
     const char *v = getenv(name);
     return v && *v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 // workgroup size for the spatial kernel by sort size (tuning override: MCP_FPS_T)

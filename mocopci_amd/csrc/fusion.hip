@@ -17,7 +17,7 @@
 //   * softmax over the 64 neighbours and the weighted coordinate sum are wave reductions.
 // Per point: 392 MFMAs (1.6 MFLOP); HBM traffic is the compulsory idx + coordinates + output.
 //
-// fp32 on the bf16 matrix pipe (default; MCP_FUSION_F32_MFMA=1 selects the f32-input MFMA build for A/B runs): layers 2 and 3
+// fp32 on the bf16 matrix pipe (the f32-input MFMA form exists only in -DMCP_AB builds, for A/B runs): layers 2 and 3
 // evaluate every fp32 product from the exact three-way bf16 split of mfma_split.h -- six bf16 MFMAs per 16 k-values instead
 // of eight f32-input ones.  The weight pieces are split once while staging to LDS; an activation tile is split in registers
 // right where the previous layer's ReLU leaves it, in the accumulator layout.
@@ -33,13 +33,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int C1 = 64, C2 = 64, NB = 64;  // layer widths 4 -> 64 -> 64 -> 128  // mocopci.py:749-755, fusion k = 32 + 32
 constexpr int WAVES = 4;
 
-// LDS image (floats):
-//   w1 [2 tiles][2 ksteps][64 lanes]                      256
-//   w2 [2 tiles][8 kquads][64 lanes][4]                  4096
-//   w3 [4 tiles][8 kquads][64 lanes][4]                  8192
-//   b1 [2 tiles][2 halves][16], b2 same, b3 [4][2][16]    64 + 64 + 128
-constexpr int OFF_W1 = 0, OFF_W2 = 256, OFF_W3 = OFF_W2 + 4096, OFF_B1 = OFF_W3 + 8192, OFF_B2 = OFF_B1 + 64,
-              OFF_B3 = OFF_B2 + 64, LDS_FLOATS = OFF_B3 + 128;
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -54,6 +47,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+#ifdef MCP_AB  // A/B builds only (make AB=1): the f32-input MFMA form of the kernel, 2.54 ms against 1.30 ms per 24x8192 launch
+// LDS image (floats):
+//   w1 [2 tiles][2 ksteps][64 lanes]                      256
+//   w2 [2 tiles][8 kquads][64 lanes][4]                  4096
+//   w3 [4 tiles][8 kquads][64 lanes][4]                  8192
+//   b1 [2 tiles][2 halves][16], b2 same, b3 [4][2][16]    64 + 64 + 128
+constexpr int OFF_W1 = 0, OFF_W2 = 256, OFF_W3 = OFF_W2 + 4096, OFF_B1 = OFF_W3 + 8192, OFF_B2 = OFF_B1 + 64,
+              OFF_B3 = OFF_B2 + 64, LDS_FLOATS = OFF_B3 + 128;
 __global__ __launch_bounds__(64 * WAVES, 2) void fusion_kernel(long long total, int n, const float *__restrict__ p1,
                                                             const float *__restrict__ p2, const int *__restrict__ idx, const int *__restrict__ idx2,
                                                             const float *__restrict__ w1, const float *__restrict__ b1,
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_kernel(long long total, 
         }
     }
 }
+#endif  // MCP_AB
 
 
 // ---- split-bf16 build ------------------------------------------------------------------------------------------------------
@@ -291,20 +293,27 @@ MCP_EXPORT int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2
     // stream's kernels hold some CUs (the next step's FPS chains take 16-24 of them, workgroups that leave no room for one of
     // these) a 2-round grid ends on the slowest slots -- measured 1.63 ms in the step against 1.34 ms alone; 8 rounds let the
     // dispatcher rebalance (1.38 ms in the step) and cost nothing alone (the weight staging is ~1 % of a 48-point workgroup).
-    static const long long grid_cap = [] { const char *v = getenv("MCP_FUSION_GRID"); return (long long)(v && *v ? atoi(v) : 4096); }();
-    const unsigned grid = (unsigned)min((total + WAVES - 1) / WAVES, grid_cap);
+    long long grid_cap = 4096;
+#ifdef MCP_AB
+    static const long long env_cap = [] { const char *v = getenv("MCP_FUSION_GRID"); return (long long)(v && *v ? atoi(v) : 0); }();
+    if (env_cap >= 1) grid_cap = env_cap;
     static const bool f32_mfma = [] { const char *v = getenv("MCP_FUSION_F32_MFMA"); return v && *v == '1'; }();
+#endif
+    const unsigned grid = (unsigned)min((total + WAVES - 1) / WAVES, grid_cap);
     mcp_prof_begin(MCP_KERNEL_FUSION, s);
+#ifdef MCP_AB
     if (f32_mfma) {
         hipLaunchKernelGGL(fusion_kernel, dim3(grid), dim3(64 * WAVES), 0, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, out);
-    } else {
-        static McpPerDeviceOnce attr_once;
-        if (attr_once.need()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fusion_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
-        hipLaunchKernelGGL(fusion_split_kernel, dim3(grid), dim3(64 * WAVES), SP_LDS_BYTES, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3,
-                           out);
+        mcp_prof_end(MCP_KERNEL_FUSION, s);
+        return mcp_launch_status();
     }
+#endif
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fusion_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
+    }
+    hipLaunchKernelGGL(fusion_split_kernel, dim3(grid), dim3(64 * WAVES), SP_LDS_BYTES, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, out);
     mcp_prof_end(MCP_KERNEL_FUSION, s);
     return mcp_launch_status();
 }

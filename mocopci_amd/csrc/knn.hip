@@ -299,6 +299,7 @@ int launch_queue(int b, int q, int n, int k, const float *query, const float *re
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 64), b), dim3(64 * SPLIT), lds, s, q, n, k, query, ref, idx, dist);
     return mcp_launch_status();

@@ -220,6 +220,7 @@ int launch_build_cloud(int b, int n, int tiles, const float *xyz, float *sorted_
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(b), dim3(BT), lds, s, n, tiles, xyz, sorted_xyz, perm, boxes);
     return mcp_launch_status();
@@ -502,6 +503,7 @@ int launch_pruned_tpl(int b, int q, int n, int tiles, int k, const float *query,
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {  // lets the CU's whole 160 KB LDS count towards residency (default budget: 64 KB)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 64 / SUB), b), dim3(64), lds, s, q, n, tiles, k, query, qperm,
                        ref, rperm, boxes, idx, dist);

@@ -244,6 +244,7 @@ int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
     }
     const long long groups = (rows + 32LL * NW - 1) / (32LL * NW);
     hipLaunchKernelGGL(kern, dim3((unsigned)groups, col_blocks), dim3(64 * NW), lds, s, rows, n, sg, nseg, total_chunks, slope, packed,

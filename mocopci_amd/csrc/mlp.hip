@@ -166,6 +166,7 @@ int launch_mlp2(long long rows, int hidden, int cout, float slope, const float *
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_once.done();
     }
     const long long groups = (rows + 32LL * NW - 1) / (32LL * NW);
     hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(64 * NW), lds, s, rows, hidden, cout, slope, x, xs_, res, rs_, packed, out, os_);

@@ -39,7 +39,14 @@ def leaky(x):
 
 
 class _Node(nn.Module):
-    pass
+    """A node of the generated parameter tree.  Assigning a tensor to one of its attributes (net.x.weight = nn.Parameter(..),
+    load_state_dict(assign=True)) bumps a global epoch, which MoCoPCI's inference cache is keyed on beside the version counters."""
+    epoch = 0
+
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.Tensor):
+            _Node.epoch += 1
+        super().__setattr__(name, value)
 
 
 def _dtype(name):
@@ -119,21 +126,36 @@ class MoCoPCI(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
+        self.invalidate()
+        try:
+            return super().load_state_dict(*a, **k)
+        finally:
+            self.invalidate()  # assign=True replaces the parameter tensors themselves
+
+    def invalidate(self):
+        """Drop everything cached from the parameters (folded BatchNorms, packed kernel operands).  Needed by hand only after
+        writes the version counters do not see: `p.data.copy_()` / `p.data.mul_()` (EMA or weight-loading code that goes through
+        .data).  optimizer.step(), in-place ops on the parameters, load_state_dict (also assign=True), re-assigned parameters and
+        .to() / .cuda() are detected."""
         self._cache = None
-        return super().load_state_dict(*a, **k)
+        self.__dict__.pop("_state_tensors", None)
 
     def _state_version(self):
         """Changes whenever a parameter or buffer is written in place (optimizer.step(), a training forward's running statistics,
-        copy_ / load) -- everything cached from them (folded BatchNorms, packed kernel operands) is then stale."""
+        copy_ / load) or REPLACED by another tensor (load_state_dict(assign=True), net.x.weight = nn.Parameter(...)) -- everything
+        cached from them (folded BatchNorms, packed kernel operands) is then stale (assignments bump _Node.epoch)."""
         ts = self.__dict__.get("_state_tensors")
-        if ts is None:  # the module tree is fixed after construction: walk it once (the walk costs more than a forward's other bookkeeping)
-            ts = self.__dict__["_state_tensors"] = [*self.parameters(), *self.buffers()]
-        return sum(t._version for t in ts)
+        if ts is None or ts[0] != _Node.epoch:  # the module tree is fixed after construction: walked again only after an assignment
+            ts = self.__dict__["_state_tensors"] = (_Node.epoch, [*self.parameters(), *self.buffers()])
+        v = 0
+        for t in ts[1]:
+            v += t._version
+        return (v, ts[0])
 
     def _check_cache(self):
         """Once per forward: drop the inference cache if any parameter / buffer changed since it was built."""
         if self._cache is not None and self._cache.get(("state_version",)) != self._state_version():
-            self._cache = None
+            self.invalidate()
 
     def _params(self):
         if self._live is not None:
@@ -277,10 +299,11 @@ class MoCoPCI(nn.Module):
         return ops.backend().group_rows(idx_self.view(torch.float32), sel).view(torch.int32)
 
     def side_stream(self, device, which=0):
-        """Extra HIP streams beside the caller's.  0: the serial FPS chains (one workgroup per batch element, latency-
-        bound), which overlap with the KNN / PointConv work of the main stream.  1: branches that depend only on encoder
-        features (see Early).  One set per caller stream, so forwards issued on different streams stay independent.
-        CPU backends run inline."""
+        """Extra HIP streams beside the caller's.  0: the encoder's serial FPS chains (one workgroup per batch element, latency-
+        bound), which overlap with the KNN / PointConv work of the main stream.  1-3: branches that depend only on encoder
+        features (see Early).  4: the level-0 self search.  5: the refinement stage's FPS (a lane of its own: the NEXT batch's
+        pyramid may already be queued on lane 0).  One set per caller stream, so forwards issued on different streams stay
+        independent.  CPU backends run inline."""
         if device.type != "cuda" or self._live is not None:  # a training forward runs on one stream (autograd replays it in order)
             return None
         key = (device.index, torch.cuda.current_stream(device).stream_id, which)
@@ -846,7 +869,7 @@ class MoCoPCI(nn.Module):
         warped = pc0 + up_flow
         # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022)
         wf = f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev)
-        side = self.side_stream(dev)
+        side = self.side_stream(dev, 5)  # NOT lane 0: the next batch's sampling pyramid is queued there (prefetch) and must not wait for this
         if side is not None:
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
@@ -893,7 +916,43 @@ class MoCoPCI(nn.Module):
             flows_b.append([p2[l] + lv[l][B:, 2 - i] for i in range(3)])
         return flows_f, flows_b, out_lst
 
-    def forward(self, xyz1, xyz2, gt=None, t=None, train=False, inputs_ready=None):
+    def prefetch(self, xyz1, xyz2, inputs_ready=None):
+        """Issue NOW everything of an inference forward on (xyz1, xyz2) that depends on nothing but the inputs -- the channel-last
+        layout, the encoder's furthest-point-sampling pyramid (a ~2.5 ms chain of latency-bound kernels on 16 CUs) and the level-0
+        self search -- on side streams, and return a handle for forward(..., prefetched=handle).  A serving loop calls it for batch
+        k+1 while batch k is still being computed (forward(then_prefetch=...) does so right after batch k's encoder is enqueued),
+        so the sampling chains run under batch k's decoder instead of stalling batch k+1's encoder.  inputs_ready: an event after
+        which the inputs are complete (a loader's copy-stream event); without it the work is ordered behind the current stream.
+        The inputs must stay unmodified until the consuming forward has run.  Returns None on backends without streams."""
+        dev = xyz1.device
+        side = self.side_stream(dev)
+        if side is None:
+            return None
+        main = torch.cuda.current_stream(dev)
+        if inputs_ready is not None:
+            side.wait_event(inputs_ready)
+        else:
+            side.wait_stream(main)
+        scope = {}
+        with torch.no_grad(), ops.backend().cloud_scope(scope):
+            with torch.cuda.stream(side):
+                xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
+                laid_out = torch.cuda.Event()
+                laid_out.record(side)
+            xyz.record_stream(main)
+            pyramid = self.sample_pyramid(xyz, side)
+            # the level-0 self search (0.6 ms with its sorted cloud) on a lane of its own, so that it neither delays the sampling
+            # chain nor waits for it
+            self_search = self.early_self_search(xyz, laid_out, main)
+        return {"inputs": (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)), "stream": main.stream_id, "xyz": xyz, "laid_out": laid_out,
+                "pyramid": pyramid, "self_search": self_search, "scope": scope}
+
+    def take_prefetched(self):
+        """The handle forward(then_prefetch=...) produced (None if it did not); hands it over once."""
+        h, self._next = self.__dict__.get("_next"), None
+        return h
+
+    def forward(self, xyz1, xyz2, gt=None, t=None, train=False, inputs_ready=None, prefetched=None, then_prefetch=None):
         """MoCoPCI.forward (mocopci.py:1069-1097): xyz1, xyz2 (B,3,N) -> out_lst, 3 x (B,N,3).
         train=True: (frames_lst_f, frames_lst_b, gt_frame, out_lst) as the reference returns, computed with autograd enabled so
         that train.py:135-160's loss can be back-propagated: gradients reach every parameter through the fused kernels
@@ -904,35 +963,32 @@ class MoCoPCI(nn.Module):
         drop_path_rate (torch's device RNG; the fused MLP / attention kernels give way to their unfused forms where a mask sits
         between their stages); after net.eval() (the constructor's state) the same call differentiates the inference graph
         (running statistics, no dropout).  A forward with train=False is always the inference graph.
-        inputs_ready (inference, optional): a torch.cuda.Event after which xyz1 / xyz2 are complete (e.g. recorded by the loader's
-        copy stream).  The furthest-point-sampling pyramid of the encoder depends on nothing but the inputs and is a 1.5 ms chain
-        of latency-bound kernels on 16 CUs; with the event it is issued on the side stream behind THAT event instead of behind
-        the caller's whole stream, so in a loop of forwards it runs under the tail of the previous call (pipelining of
-        consecutive batches; a single isolated call is unchanged).  Without it the stream-ordered default applies."""
+        Pipelining of consecutive batches (inference, optional; a single isolated call is unchanged without them):
+        inputs_ready: a torch.cuda.Event after which xyz1 / xyz2 are complete: the input-only work (see prefetch) is issued behind
+        THAT event instead of behind the caller's whole stream, so in a loop of forwards it overlaps the previous call's tail.
+        prefetched: the handle of an earlier prefetch(xyz1, xyz2) -- that work is then not issued again.
+        then_prefetch: (next_xyz1, next_xyz2[, ready event]) -- once this call's encoder is enqueued, prefetch() the NEXT batch, so
+        its sampling chains run under this call's decoder; the handle is collected with take_prefetched()."""
         B = xyz1.shape[0]
         self._check_cache()
         if not train:
-            with torch.no_grad(), ops.backend().cloud_scope():
+            h = prefetched
+            if h is None and inputs_ready is not None:
+                h = self.prefetch(xyz1, xyz2, inputs_ready)
+            with torch.no_grad(), ops.backend().cloud_scope(None if h is None else h["scope"]):
                 pyramid = self_search = None
-                side = self.side_stream(xyz1.device) if inputs_ready is not None else None
-                if side is not None:
+                if h is not None:
                     main = torch.cuda.current_stream(xyz1.device)
-                    side.wait_event(inputs_ready)
-                    with torch.cuda.stream(side):
-                        xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
-                        laid_out = torch.cuda.Event()
-                        laid_out.record(side)
-                    xyz.record_stream(main)
-                    pyramid = self.sample_pyramid(xyz, side)
-                    # the level-0 self search (0.6 ms with its sorted cloud) is input-only as well: on a lane of its own, so that it
-                    # neither delays the sampling chain nor waits for it (-0.15 ms per step; MCP_NO_EARLY_SEARCH=1 for A/B runs)
-                    if os.environ.get("MCP_NO_EARLY_SEARCH") != "1":
-                        self_search = self.early_self_search(xyz, laid_out, main)
-                    main.wait_event(laid_out)
+                    if h["inputs"] != (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)) or h["stream"] != main.stream_id:
+                        raise RuntimeError("prefetched handle belongs to other inputs or another stream")
+                    xyz, pyramid, self_search = h["xyz"], h["pyramid"], h["self_search"]
+                    main.wait_event(h["laid_out"])
                 else:
                     xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
                 self._early = Early(self, xyz.device)
                 pcs, feats = self.run_encoder(xyz, self._early, pyramid=pyramid, self_search=self_search)
+                if then_prefetch is not None:
+                    self._next = self.prefetch(*then_prefetch)
                 return self.run_decoder(pcs, feats, B)
         xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
         self._live = {**dict(self.named_parameters()), **dict(self.named_buffers())}

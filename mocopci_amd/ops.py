@@ -13,7 +13,6 @@ no CPU fallback (a CPU tensor raises).
 """
 import contextlib
 import ctypes
-import os
 import threading
 
 import torch
@@ -101,8 +100,9 @@ class HipBackend:
         return out
 
     # clouds at least this large go through the Morton-sorted, box-pruned search (same results)
-    PRUNE_MIN_REFS = int(os.environ.get("MCP_PRUNE_MIN_REFS", "2048"))
-    PRUNE_MIN_QUERIES = int(os.environ.get("MCP_PRUNE_MIN_QUERIES", "1024"))
+    # (plain attributes: A/B tools set them on the class; the package reads no tuning variables from the environment)
+    PRUNE_MIN_REFS = 2048
+    PRUNE_MIN_QUERIES = 1024
 
     def __init__(self):
         self._tls = threading.local()  # .scope: {key: (tensor, sorted cloud, stream, built-event)} while a cloud_scope is open
@@ -115,19 +115,20 @@ class HipBackend:
         return self._tile
 
     @contextlib.contextmanager
-    def cloud_scope(self):
+    def cloud_scope(self, seed=None):
         """Within this context the Morton-sorted form of a cloud is built once per tensor and reused by every search on it
         (the model searches the same clouds many times per forward).  The caller promises not to write into a cloud tensor
         while the scope is open -- model.forward opens one per call and never does.  Entries hold a strong reference to their
         tensor, so its storage cannot be recycled under the key; the scope is per thread and dropped on exit.  Outside a scope
-        nothing is cached: every search rebuilds (one extra launch), so buffers a caller reuses between calls are always safe."""
+        nothing is cached: every search rebuilds (one extra launch), so buffers a caller reuses between calls are always safe.
+        seed: a dict to use as this scope's table (MoCoPCI.prefetch fills one ahead of the forward that then opens its scope on
+        it); a seeded scope replaces an enclosing one until it exits."""
         outer = getattr(self._tls, "scope", None)
-        self._tls.scope = {} if outer is None else outer
+        self._tls.scope = seed if seed is not None else ({} if outer is None else outer)
         try:
             yield
         finally:
-            if outer is None:
-                self._tls.scope = None
+            self._tls.scope = outer
 
     def _build_cloud(self, xyz):
         B, N, _ = xyz.shape
@@ -372,6 +373,8 @@ class HipBackend:
         hd = C // heads
         if scale is None:
             scale = hd ** -0.5
+        if hd not in (8, 16, 32, 64, 256):  # head dims neither kernel is built for: the dense formulation (same arithmetic as the twin)
+            return grad.attention_twin(q, kv, heads, float(scale))
         return grad.run(self._attention, grad.attention_twin, q, kv, heads, float(scale))
 
     def _attention(self, q, kv, heads, scale):
@@ -421,11 +424,12 @@ class HipBackend:
         ks = (ctypes.c_int * len(ps))(*[p.shape[1] for p in ps])
         return _lib.load().mcp_linear_packed_floats(n, len(ps), ks) != 0
 
-    _NO_LINEAR = os.environ.get("MCP_NO_LINEAR", "0") == "1"
-    _NO_NARROW = os.environ.get("MCP_NO_NARROW", "0") == "1"
-    _LIN_MIN_ROWS = int(os.environ.get("MCP_LINEAR_MIN_ROWS", "16384"))
-    _LIN_MAX_K = int(os.environ.get("MCP_LINEAR_MAX_K", "320"))
-    _LIN_MAX_N = int(os.environ.get("MCP_LINEAR_MAX_N", "192"))
+    # shape policy of the fused Linear (measured optimum; tools/linear_ab.py overrides them on the class)
+    _NO_LINEAR = False
+    _NO_NARROW = False
+    _LIN_MIN_ROWS = 16384
+    _LIN_MAX_K = 320
+    _LIN_MAX_N = 192
 
     def linear_pack(self, w, b, ks):
         """Operand image of one Linear whose K axis is the concatenation of pieces of widths ks (split once per layer)."""
@@ -509,10 +513,10 @@ class HipBackend:
         return grad.run(fused, grad.mlp2_twin, x, res, w1, b1, w2, b2, slope)
 
     def mlp2_supported(self, cin, hidden, cout):
-        """Shapes the fused kernel is built for (the ones where it beats the BLAS chain); MCP_NO_MLP2=1 turns it off for A/B runs."""
+        """Shapes the fused kernel is built for (the ones where it beats the BLAS chain); A/B tools set _NO_MLP2 on the class."""
         return not self._NO_MLP2 and _lib.load().mcp_mlp2_packed_floats(cin, hidden, cout) != 0
 
-    _NO_MLP2 = os.environ.get("MCP_NO_MLP2", "0") == "1"
+    _NO_MLP2 = False
 
     def chamfer(self, x, y):
         """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor.  As a training loss

@@ -13,7 +13,7 @@ class OracleBackend:
     def prebuild_cloud(self, xyz):
         pass
 
-    def cloud_scope(self):
+    def cloud_scope(self, seed=None):
         import contextlib
         return contextlib.nullcontext()
 

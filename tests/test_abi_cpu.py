@@ -3,6 +3,8 @@ declares; the ctypes signature table matches the header's argument counts.  No c
 import os
 import re
 
+import pytest
+
 from mocopci_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,6 @@
 """The main-stream kernels of one step in launch order with duration, grid and workgroup size (rocprofv3 --kernel-trace database):
 long launches with few waves are the ones that leave the chip idle on the critical path.
-usage: python tools/step_timeline.py <results.db>"""
+usage: python tools/step_timeline.py <results.db> [--all]     (--all: every queue, with the queue id in front)"""
 import re
 import sqlite3
 import sys
@@ -19,7 +19,7 @@ for r in step:
 main_q = max(busy, key=busy.get)
 t0 = step[0][1]
 for r in step:
-    if r[3] != main_q:
+    if r[3] != main_q and "--all" not in sys.argv:
         continue
     name = re.sub(r"\(anonymous namespace\)::|void |at::native::", "", r[0])
     name = "GEMM(hipBLASLt)" if name.startswith("Cijk") else re.sub(r"\(.*", "", name)[:60]
@@ -30,4 +30,4 @@ for r in step:
         threads *= max(v, 1)
     waves = threads // 64
     flag = " <-- under 2 waves/SIMD" if (r[2] - r[1]) > 15000 and waves < 2048 else ""
-    print(f"+{(r[1] - t0) / 1e6:7.3f} ms {(r[2] - r[1]) / 1e3:8.1f} us  waves {waves:7d}  wg {w}  {name}{flag}")
+    print(("" if "--all" not in sys.argv else f"q{r[3]} ") + f"+{(r[1] - t0) / 1e6:7.3f} ms {(r[2] - r[1]) / 1e3:8.1f} us  waves {waves:7d}  wg {w}  {name}{flag}")
