@@ -89,11 +89,14 @@ static inline int mcp_launch_status() {
 static inline unsigned mcp_divup(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // A pair of floats with element-wise arithmetic -- deliberately NOT an ext-vector type, and the library is built with
-// -fno-slp-vectorize: no packed-fp32 instruction (v_pk_add/mul/fma_f32) may be formed.  On MI355X (ROCm 7.2 compiler) kernels
-// using them returned wrong values, rarely and timing-dependently, while a bf16-MFMA-heavy kernel of another stream shared the
-// chip: furthest point sampling picked different points in ~8 % of its launches beside the fusion kernel (tools/fps_under_load.py;
-// never alone, never in the scalar build), and the fusion kernel's own packed epilogue lost lanes of its x-sum when its
-// instruction timing changed (tools/fusion_race.py).  DESIGN.md section 6.
+// -fno-slp-vectorize -fno-vectorize: no packed-fp32 instruction (v_pk_add/mul/fma_f32) may be formed.  Cause, established in round 3
+// (tools/ab/): a v_pk_*_f32 result needs more wait states before its consumer than this compiler inserts.
+// It inserts ONE, and only for VALU consumers, and only because the packed op's src0 op_sel_hi bit aliases the DST_OP_SEL bit
+// of its dst-sel forwarding check (a packed op with op_sel_hi:[0,..] gets none); DS / VMEM consumers get none at all.  Observed:
+// the fusion epilogue's `v_pk_add_f32 v[0:1]; ds_bpermute_b32 v2, v109, v0` (0 wait states) lost exactly one butterfly step of
+// the x-sum, and furthest point sampling beside the fusion kernel picked different points in 7 of 180 launches with
+// `v_pk_fma_f32; s_nop 0; v_min_f32` (1 wait state), 1 of 180 with two, 0 of 180 with three (s_nop 1 after every packed op) and
+// 0 of 180 in the scalar build -- with or without the LDS index buffering that went in with the same commit.
 struct mcp_f2 {
     float x, y;
 };
@@ -111,11 +114,13 @@ __device__ __forceinline__ long long mcp_div(long long a, int b, bool fits32) {
 }
 __device__ __forceinline__ bool mcp_fits32(long long total) { return total <= 0xFFFFFFFFLL; }
 
-// Raw max / min / relu.  fmaxf()/fminf() first canonicalise any operand the compiler cannot prove quiet (MFMA results,
-// loads, DPP outputs): an extra v_max_f32 x,x per operand.  The kernels' values are never signalling NaNs, so the
-// hot loops use the bare instructions.  NEVER feed these an MFMA result directly: the compiler does not see into the
-// asm, so it inserts none of the wait states an MFMA -> VALU read needs (measured: wrong results); pass MFMA outputs
-// through a compiler-visible instruction first.
+// Raw max / min / relu.  fmaxf()/fminf() first canonicalise any operand the compiler cannot prove quiet (loop-carried values,
+// loads, DPP outputs): an extra v_max_f32 x,x per operand.  The kernels' values are never signalling NaNs, so the hot loops use
+// the bare instructions.  Inline asm is invisible to the compiler's hazard recogniser: it is not a "VALU" for the MFMA -> VALU,
+// transcendental -> VALU or VALU -> v_readlane / v_permlane*_swap rules.  So: NEVER feed these an MFMA or v_exp/v_rcp result
+// directly and never read their result with readlane / permlane-swap directly (pass through a compiler-visible instruction) --
+// and because that is a property of the surrounding code, tools/isa_lint.py checks the final instruction stream of every
+// kernel for exactly these distances (tests/test_isa_lint_cpu.py).
 __device__ __forceinline__ float mcp_max_raw(float a, float b) {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -124,15 +129,5 @@ __device__ __forceinline__ float mcp_max_raw(float a, float b) {
 __device__ __forceinline__ float mcp_min_raw(float a, float b) {
     float r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float mcp_max3_raw(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float mcp_relu_raw(float a) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
     return r;
 }

@@ -79,10 +79,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
     extern __shared__ float4 smem_f4[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_f4);  // [3] rotating max slots (+pad to 64 B)
     float *sxyz = reinterpret_cast<float *>(smem_f4) + 16;                        // [n*3] when LDS_XYZ
-    // [m] selected indices, written out once at the end.  Not only because a global store per iteration sits in front of every
-    // barrier: with a store of the wave still outstanding while the next iteration's packed-fp32 scan ran, the kernel returned
-    // different samples when the memory system was busy with another stream's kernels (never on an idle chip) -- the same
-    // packed-op-beside-an-outstanding-memory-operation pattern as the fusion prefetch experiment.
+    // [m] selected indices, written out once at the end: a global store per iteration would sit in front of every barrier
     int *sidx = reinterpret_cast<int *>(sxyz + (LDS_XYZ ? n * 3 : 0));
 
     const int tid = threadIdx.x;
@@ -184,7 +181,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
         FPS_STAMP(2);  // wave reductions + index select
         if (W > 1) {
             // cross-wave: one LDS atomic max per wave on a rotating slot, one barrier, one broadcast read
-            if (lane == 0) atomicMax(&slots[s_cur], ((unsigned long long)hi << 32) | wlo);
+            if (lane == 0) __hip_atomic_fetch_max(&slots[s_cur], ((unsigned long long)hi << 32) | wlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (tid == 0) slots[s_nxt] = 0ull;
             __syncthreads();
             FPS_STAMP(3);  // LDS atomic + barrier
@@ -351,7 +348,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
         // exact lower bound of the lane's point distances (see the header comment); an all-padding lane has best = -1
         // (lo - c, c - hi) per axis as one packed add: (lo, -hi) + (-c, c)
         const f2 tx = bx + f2{-x1, x1}, ty = by + f2{-y1, y1}, tz = bz + f2{-z1, z1};
-        const float ex = mcp_max3_raw(tx.x, tx.y, 0.f), ey = mcp_max3_raw(ty.x, ty.y, 0.f), ez = mcp_max3_raw(tz.x, tz.y, 0.f);
+        const float ex = fmaxf(fmaxf(tx.x, tx.y), 0.f), ey = fmaxf(fmaxf(ty.x, ty.y), 0.f), ez = fmaxf(fmaxf(tz.x, tz.y), 0.f);
         const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
         const bool need = lb < best;
         FPS_STAMP(1);  // box test
@@ -378,9 +375,9 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
         }
         FPS_STAMP(2);  // update + wave reductions
         if (lane == 0) {
-            // plain ds_max_u64 (atomicMax() would wrap it in a second, redundant first-active-lane election)
-            const unsigned long long key = ((unsigned long long)c_hi << 32) | c_lo;
-            asm volatile("ds_max_u64 %0, %1" ::"v"((uint32_t)(size_t)&slots[s_cur]), "v"(key) : "memory");  // low word of a flat LDS address = LDS offset
+            // one ds_max_u64, visible to the wait-count pass (the Makefile turns the atomic optimizer off for this file: it would
+            // wrap the atomic in a second, redundant first-active-lane election)
+            __hip_atomic_fetch_max(&slots[s_cur], ((unsigned long long)c_hi << 32) | c_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (tid == 0) slots[s_nxt] = 0ull;
         __syncthreads();
@@ -649,8 +646,7 @@ __global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles
             c_hi = whi;
         }
         if (lane == 0) {
-            const unsigned long long key = ((unsigned long long)c_hi << 32) | c_lo;
-            asm volatile("ds_max_u64 %0, %1" ::"v"((uint32_t)(size_t)&slots[s_cur]), "v"(key) : "memory");
+            __hip_atomic_fetch_max(&slots[s_cur], ((unsigned long long)c_hi << 32) | c_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (tid == 0) slots[s_nxt] = 0ull;
         __syncthreads();  // also orders this iteration's tcand writes before the read below
