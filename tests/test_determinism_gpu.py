@@ -154,3 +154,31 @@ def test_back_to_back_pipelined_forwards_are_bit_identical():
     torch.cuda.synchronize()
     for k, o in enumerate(outs):
         assert all(torch.equal(a, b) for a, b in zip(o, alone)), f"pipelined call {k} differs from the isolated call"
+
+
+def test_prefetched_forwards_are_bit_identical_to_an_isolated_call():
+    """The serving loop of bench.py: prefetch(batch k+1) is issued right after batch k's encoder is enqueued and consumed by the
+    next forward.  Every call must return exactly what an isolated call returns; a handle for other inputs is refused."""
+    from mocopci_amd import synth
+    from tests import harness_checks as hc
+    net = hc.build_model(DEV)
+    x1, x2, _ = synth.make_batch(2, 8, 8192, device=DEV)
+    y1, y2, _ = synth.make_batch(2, 8, 8192, device=DEV, first_sample=8)
+    alone_x = net(x1, x2)
+    alone_y = net(y1, y2)
+    torch.cuda.synchronize()
+    batches = [(x1, x2, alone_x), (y1, y2, alone_y), (x1, x2, alone_x), (x1, x2, alone_x)]
+    h = net.prefetch(*batches[0][:2])
+    outs = []
+    for k, (a, b, _) in enumerate(batches):
+        nxt = batches[k + 1][:2] if k + 1 < len(batches) else None
+        outs.append(net(a, b, prefetched=h, then_prefetch=nxt))
+        h = net.take_prefetched()
+    assert h is None
+    torch.cuda.synchronize()
+    for k, (o, (_, _, want)) in enumerate(zip(outs, batches)):
+        assert all(torch.equal(p, q) for p, q in zip(o, want)), f"prefetched call {k} differs from the isolated call"
+    h = net.prefetch(x1, x2)
+    with pytest.raises(RuntimeError):
+        net(y1, y2, prefetched=h)
+    torch.cuda.synchronize()

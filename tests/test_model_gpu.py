@@ -133,3 +133,24 @@ def test_inputs_ready_event_pipelines_without_changing_results():
             assert torch.equal(u, got[k % 2][j])                                   # the same call again: same bits
             elem, pts, worst, mse = hc.frame_deviation(u.cpu().numpy(), v.cpu().numpy())
             assert elem <= 0.02 and pts <= hc.POINT_BUDGET and worst <= hc.MAX_DISP_BUDGET and mse <= hc.MSE_BUDGET, (k, j, elem, pts, worst, mse)
+
+
+def test_bench_two_ranks_rehearsal_as_child_process():
+    """The path the driver's multi-GPU run takes (`python bench.py --gpus N` fans out to torch.distributed.run, one rank per
+    device, final all_gather of the frames), rehearsed with two ranks on this one GPU over gloo: a FRESH child process (this
+    process has initialised the GPU and must not exec), one JSON line, both ranks seen, weak scaling of the batch."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["n_ranks_seen"] == 2
+    assert res["config"]["global_batch"] == 16 and res["scaling"] == "weak"
+    assert res["value"] > 0 and res["metric"] == "interpolated frames/sec"
