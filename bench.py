@@ -212,8 +212,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="do not pipeline the input-only sampling pyramid across consecutive steps")
-    ap.add_argument("--pipeline", choices=("prefetch", "event"), default="prefetch",
-                    help="prefetch: the next step's input-only work is issued under this step's decoder; event: issued at the next call (round 2)")
+    ap.add_argument("--pipeline", choices=("two-batch", "prefetch", "event"), default="two-batch",
+                    help="two-batch: prefetch + the tail of batch k-1 (after its refinement-stage sampling) is enqueued behind the first part of "
+                         "batch k; prefetch: the next step's input-only work is issued under this step's decoder; event: issued at the next call (round 2)")
     ap.add_argument("--streams", type=int, default=1, help="steps in flight: consecutive steps issued round-robin on this many HIP streams "
                                                             "(measured: 2-3 give 0-10 %% depending on how the runtime maps the ~15 streams onto its 4 "
                                                             "hardware queues, not reproducibly; more hardware queues make it worse)")
@@ -269,22 +270,35 @@ def main():
     counter = [0]
 
     handle = [None]
+    pending = [None]
 
     def step(last=False):
-        """One forward.  Default pipelining: the input-only work of the NEXT step (sampling pyramid, level-0 self search) is issued
-        right after this step's encoder is enqueued (MoCoPCI.forward(then_prefetch=...)) and consumed by the next call.  `last`:
-        no next step -- nothing is prefetched, so a phase (warm-up, timed region, instrumented pass) issues exactly one pyramid
-        per step of its own: none is borrowed from the phase before, none is left over."""
+        """One step of the serving loop.  Default pipelining ("two-batch"): consecutive batches are software-pipelined on one stream --
+        this call enqueues batch k's forward up to the launch of its refinement-stage furthest point sampling (MoCoPCI.begin),
+        then the rest of batch k-1 (MoCoPCI.finish), so that sampling chain runs beside real work instead of stalling the stream; the
+        input-only work of batch k+1 is issued right after batch k's encoder (then_prefetch).  `last`: the phase ends here -- batch
+        k is finished too and nothing is prefetched, so a phase (warm-up, timed region, instrumented pass) contains exactly one
+        pyramid, one first part and one second part per step of its own: nothing is borrowed from the phase before, nothing is
+        left over.  Returns the frames of the most recently finished batch."""
         ln = lanes[counter[0] % n_streams]
         counter[0] += 1
         with torch.cuda.stream(ln):
-            if pipeline == "prefetch":
+            if pipeline in ("two-batch", "prefetch"):
                 h = handle[0] if handle[0] is not None else net.prefetch(x1, x2, inputs_ready)
-                out = net(x1, x2, prefetched=h, then_prefetch=None if last else (x1, x2, inputs_ready))
+                nxt = None if last else (x1, x2, inputs_ready)
+                if pipeline == "two-batch":
+                    cur = net.begin(x1, x2, prefetched=h, then_prefetch=nxt)
+                    out = net.finish(pending[0]) if pending[0] is not None else None
+                    pending[0] = cur
+                    if last:
+                        out = net.finish(cur)
+                        pending[0] = None
+                else:
+                    out = net(x1, x2, prefetched=h, then_prefetch=nxt)
                 handle[0] = net.take_prefetched()
             else:
                 out = net(x1, x2, inputs_ready=inputs_ready)   # 3 x (B,N,3)
-            return shard.gather_frames(out, world)  # (world*B,3,N,3) on every rank; no-op view for world == 1
+            return None if out is None else shard.gather_frames(out, world)  # (world*B,3,N,3) on every rank; no-op view for world == 1
 
     for i in range(args.warmup):
         step(last=i == args.warmup - 1)
@@ -348,6 +362,12 @@ def main():
                    "step_pipelining": {"serial": "off (--serial)",
                                        "event": "the furthest-point-sampling pyramid and the level-0 self search of step k+1 (input-only, side streams) are issued "
                                                 "when step k+1 is called, behind the inputs' ready event, and overlap the tail of step k",
+                                       "two-batch": "consecutive batches are software-pipelined on one stream: step k enqueues batch k up to the launch of its "
+                                                    "refinement-stage furthest point sampling, then the rest of batch k-1 (Point-Transformer refinement, fusion), so that "
+                                                    "serial sampling chain overlaps the next batch's encoder; the input-only work of batch k+1 (sampling pyramid, level-0 "
+                                                    "self search) is issued right after batch k's encoder.  The last step of the timed region finishes its own batch too: "
+                                                    "exactly `steps` complete forwards (pyramids, first parts, second parts) are enqueued and completed inside the timed "
+                                                    "region; results are bit-identical to isolated forwards",
                                        "prefetch": "the furthest-point-sampling pyramid and the level-0 self search of step k+1 (input-only, side streams) are issued "
                                                    "right after step k's encoder is enqueued and run under step k's decoder; the first step of the timed region issues "
                                                    "its own and the last step prefetches nothing: exactly `steps` pyramids run inside the timed region"}[pipeline],

@@ -224,6 +224,22 @@ int mcp_attention_small(int bf, int nq, int nk, int heads, int hd, const float *
 int mcp_attention_wide(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
                         const float *v, int v_stride, float scale, float *out, int out_stride, mcp_stream_t stream);
 
+/* Both kernels behind one entry point (hd in {8, 16, 32, 64, 256}), with a rotation of the key / value batch: batch element bf of
+ * the queries attends to keys / values of batch element (bf + kv_batch_shift) mod BF (0 <= kv_batch_shift < BF).  EI_Crossformer
+ * (mocopci.py:147-151) runs Injector(x1 -> x2) and Extractor(x2 -> x1) on the two halves of one stacked batch: one launch with
+ * kv_batch_shift = BF / 2 instead of two. */
+int mcp_attention(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
+                  const float *v, int v_stride, int kv_batch_shift, float scale, float *out, int out_stride, mcp_stream_t stream);
+
+/* Row normalisation with the additions in front of it (nn.LayerNorm semantics: biased variance, eps inside the root):
+ *     z = x[r] (+ y[r]) (+ bias);   out[r] = (z - mean z) * rsqrt(var z + eps) (* gamma + beta)
+ * x, y, out (rows, c) with row strides in floats; y, bias, gamma, beta may be NULL; c <= 1024.  Replaces the LayerNorm launches
+ * of EI_Crossformer (mocopci.py:100-145: query_norm / feat_norm / ffn_norm) -- their affine parts fold into the Linear behind
+ * them -- and the residual additions in front of ffn_norm. */
+int mcp_add_layernorm(long long rows, int c, const float *x, long long x_stride, const float *y, long long y_stride,
+                      const float *bias, const float *gamma, const float *beta, float eps, float *out, long long out_stride,
+                      mcp_stream_t stream);
+
 /* chamfer_loss (models/utils.py:36-45 -> pytorch3d chamfer_distance defaults): per-point squared
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);

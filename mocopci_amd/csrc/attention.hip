@@ -28,7 +28,7 @@ __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >
 template <int HD>
 __global__ __launch_bounds__(64 * WAVES) void attention_small_kernel(int nq, int nk, int heads, const float *__restrict__ q, int qs,
                                                                      const float *__restrict__ k, int ks, const float *__restrict__ v,
-                                                                     int vs, float scale_log2e, float *__restrict__ out, int os) {
+                                                                     int vs, float scale_log2e, float *__restrict__ out, int os, int kv_shift) {
     constexpr int KS = HD + 1;  // padded K row stride (floats): A-operand reads are conflict-free
     __shared__ float kt[2][KT * KS];
     __shared__ __attribute__((aligned(16))) float vt[2][KT * HD];
@@ -37,8 +37,10 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_kernel(int nq, int
     const int qi = blockIdx.x * (32 * WAVES) + wave * 32 + col;
     const bool live = qi < nq;
     q += ((size_t)bf * nq + (live ? qi : 0)) * qs + head * HD;
-    k += (size_t)bf * nk * ks + head * HD;
-    v += (size_t)bf * nk * vs + head * HD;
+    int bkv = bf + kv_shift;  // keys / values of batch element (bf + kv_shift) mod BF (0 <= kv_shift < BF)
+    if (bkv >= (int)gridDim.z) bkv -= (int)gridDim.z;
+    k += (size_t)bkv * nk * ks + head * HD;
+    v += (size_t)bkv * nk * vs + head * HD;
 
     // B operand: Q[query][2s + h], pre-scaled so that p = exp2(s - m)
     float qf[HD / 2];
@@ -175,7 +177,7 @@ struct WideCfg {
 template <int HD>
 __global__ __launch_bounds__(64 * WAVES, 1) void attention_wide_kernel(int nq, int nk, const float *__restrict__ q, int qs,
                                                                        const float *__restrict__ k, int ks, const float *__restrict__ v,
-                                                                       int vs, float scale_log2e, float *__restrict__ out, int os) {
+                                                                       int vs, float scale_log2e, float *__restrict__ out, int os, int kv_shift) {
     using C = WideCfg<HD>;
     constexpr int KT = C::KT, KS = C::KS, TD = C::TD;
     extern __shared__ __attribute__((aligned(16))) float lds_w[];
@@ -186,8 +188,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_wide_kernel(int nq, i
     const int qi = blockIdx.x * (32 * WAVES) + wave * 32 + col;
     const bool live = qi < nq;
     q += ((size_t)bf * nq + (live ? qi : 0)) * qs + head * HD;
-    k += (size_t)bf * nk * ks + head * HD;
-    v += (size_t)bf * nk * vs + head * HD;
+    int bkv = bf + kv_shift;  // keys / values of batch element (bf + kv_shift) mod BF (0 <= kv_shift < BF)
+    if (bkv >= (int)gridDim.z) bkv -= (int)gridDim.z;
+    k += (size_t)bkv * nk * ks + head * HD;
+    v += (size_t)bkv * nk * vs + head * HD;
 
     float qf[HD / 2];
 #pragma unroll
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_wide_kernel(int nq, i
 
 template <int HD>
 int launch_wide(int bf, int nq, int nk, int heads, const float *q, int qs, const float *k, int ks, const float *v, int vs, float sl2,
-                float *out, int os, hipStream_t s) {
+                float *out, int os, int kv_shift, hipStream_t s) {
     auto kern = attention_wide_kernel<HD>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
@@ -314,10 +318,39 @@ int launch_wide(int bf, int nq, int nk, int heads, const float *q, int qs, const
         attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(nq, 32 * WAVES), heads, bf), dim3(64 * WAVES), WideCfg<HD>::LDS_BYTES, s, nq, nk, q, qs, k, ks, v,
-                       vs, sl2, out, os);
+                       vs, sl2, out, os, kv_shift);
     return mcp_launch_status();
 }
 
+}  // namespace
+
+namespace {
+int attention_any(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
+                  int v_stride, int kv_shift, float scale, float *out, int out_stride, hipStream_t s) {
+    // float4 accesses: every row start and head offset must be 16-byte aligned
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return MCP_ERR_BAD_ARG;
+    if ((q_stride | k_stride | v_stride | out_stride) & 3) return MCP_ERR_BAD_ARG;
+    if (kv_shift < 0 || kv_shift >= bf) return MCP_ERR_BAD_ARG;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const dim3 grid(mcp_divup(nq, 32 * WAVES), heads, bf);
+    int rc;
+    mcp_prof_begin(MCP_KERNEL_ATTENTION, s);
+    if (hd == 8 || hd == 16) {
+        if (hd == 8)
+            hipLaunchKernelGGL(attention_small_kernel<8>, grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2,
+                               out, out_stride, kv_shift);
+        else
+            hipLaunchKernelGGL(attention_small_kernel<16>, grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride,
+                               sl2, out, out_stride, kv_shift);
+        rc = mcp_launch_status();
+    } else {
+        rc = hd == 32   ? launch_wide<32>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, kv_shift, s)
+             : hd == 64 ? launch_wide<64>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, kv_shift, s)
+                        : launch_wide<256>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, kv_shift, s);
+    }
+    mcp_prof_end(MCP_KERNEL_ATTENTION, s);
+    return rc;
+}
 }  // namespace
 
 MCP_EXPORT int mcp_attention_small(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k,
@@ -325,21 +358,7 @@ MCP_EXPORT int mcp_attention_small(int bf, int nq, int nk, int heads, int hd, co
                                    mcp_stream_t stream) {
     MCP_CHECK_ARGS(bf > 0 && nq > 0 && nk > 0 && heads > 0 && q && k && v && out);
     if (hd != 8 && hd != 16) return MCP_ERR_UNSUPPORTED;
-    // float4 accesses: every row start and head offset must be 16-byte aligned
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return MCP_ERR_BAD_ARG;
-    if ((q_stride | k_stride | v_stride | out_stride) & 3) return MCP_ERR_BAD_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const float sl2 = scale * 1.44269504088896340736f;
-    const dim3 grid(mcp_divup(nq, 32 * WAVES), heads, bf);
-    mcp_prof_begin(MCP_KERNEL_ATTENTION, s);
-    if (hd == 8)
-        hipLaunchKernelGGL(attention_small_kernel<8>, grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2,
-                           out, out_stride);
-    else
-        hipLaunchKernelGGL(attention_small_kernel<16>, grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride,
-                           sl2, out, out_stride);
-    mcp_prof_end(MCP_KERNEL_ATTENTION, s);
-    return mcp_launch_status();
+    return attention_any(bf, nq, nk, heads, hd, q, q_stride, k, k_stride, v, v_stride, 0, scale, out, out_stride, (hipStream_t)stream);
 }
 
 MCP_EXPORT int mcp_attention_wide(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k,
@@ -347,14 +366,14 @@ MCP_EXPORT int mcp_attention_wide(int bf, int nq, int nk, int heads, int hd, con
                                   mcp_stream_t stream) {
     MCP_CHECK_ARGS(bf > 0 && nq > 0 && nk > 0 && heads > 0 && q && k && v && out);
     if (hd != 32 && hd != 64 && hd != 256) return MCP_ERR_UNSUPPORTED;
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return MCP_ERR_BAD_ARG;
-    if ((q_stride | k_stride | v_stride | out_stride) & 3) return MCP_ERR_BAD_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const float sl2 = scale * 1.44269504088896340736f;
-    mcp_prof_begin(MCP_KERNEL_ATTENTION, s);
-    const int rc = hd == 32   ? launch_wide<32>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, s)
-                   : hd == 64 ? launch_wide<64>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, s)
-                              : launch_wide<256>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, s);
-    mcp_prof_end(MCP_KERNEL_ATTENTION, s);
-    return rc;
+    return attention_any(bf, nq, nk, heads, hd, q, q_stride, k, k_stride, v, v_stride, 0, scale, out, out_stride, (hipStream_t)stream);
+}
+
+MCP_EXPORT int mcp_attention(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
+                             const float *v, int v_stride, int kv_batch_shift, float scale, float *out, int out_stride,
+                             mcp_stream_t stream) {
+    MCP_CHECK_ARGS(bf > 0 && nq > 0 && nk > 0 && heads > 0 && q && k && v && out);
+    if (hd != 8 && hd != 16 && hd != 32 && hd != 64 && hd != 256) return MCP_ERR_UNSUPPORTED;
+    return attention_any(bf, nq, nk, heads, hd, q, q_stride, k, k_stride, v, v_stride, kv_batch_shift, scale, out, out_stride,
+                         (hipStream_t)stream);
 }

@@ -97,6 +97,7 @@ class MoCoPCI(nn.Module):
     attn_drop_rate = 0.05   # dropout on the softmax matrices of Multi_Frame_Att / Cross_Frame_Att
     drop_path_rate = 0.04   # stochastic depth of Multi_Frame_Att's two residual branches (Cross_Frame_Att: 0)
     BN_MOMENTUM = 0.1       # nn.BatchNorm default
+    FOLD_EI = True          # inference: EI cross-formers in their folded 9-launch form (A/B: tools/step_time.py net.FOLD_EI=0)
 
     def __init__(self):
         super().__init__()
@@ -118,6 +119,14 @@ class MoCoPCI(nn.Module):
         self._live = None  # training forward: {name: live parameter / buffer}; derived tensors are then rebuilt, not cached
         self._mode = None  # training forward in net.train() mode: (drop, attn_drop, drop_path) -- BatchNorm then uses batch statistics
         self.eval()
+
+    def _mark(self, name):
+        """Timeline marker (tools/step_sections.py sets self._marks = []): an event on the current stream; nothing otherwise."""
+        marks = self.__dict__.get("_marks")
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
 
     # ---- parameter access ---------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -369,6 +378,7 @@ class MoCoPCI(nn.Module):
             if side is not None:
                 main.wait_event(ready[lvl])
 
+        self._mark("enc start")
         f0 = self.conv1d_block(xyz, p + "level0_lift")
         if self_search is not None:
             idx0, found = self_search
@@ -397,24 +407,28 @@ class MoCoPCI(nn.Module):
         def branches(lvl, f):  # decoder work that needs nothing but this level's encoder features (both frames stacked)
             if early is None:
                 return
-            early.launch(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:])), lane=lvl)
+            early.launch(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:], stacked=f)), lane=lvl)
             early.launch(("cos", lvl), lambda: ops.backend().knn_cosine(f, swap(f), 16), lane=lvl)
 
         branches(1, f1)
         if early is not None:
             early.launch("i3_01", lambda: ops.backend().interp3_search(xyz, pc1), lane=1)
         f1_2 = self.conv1d_block(f1, p + "level1_1")
+        self._mark("enc level1 done")
         need(2)
         f2 = self.pointconv(p + "level2", pc1, pc2, f1_2)
         f2 = self.conv1d_block(f2, p + "level2_0")
         branches(2, f2)
         f2_3 = self.conv1d_block(f2, p + "level2_1")
+        self._mark("enc level2 done (before need 3)")
         need(3)
         f3 = self.pointconv(p + "level3", pc2, pc3, f2_3)
         f3 = self.conv1d_block(f3, p + "level3_0")
         f3_4 = self.conv1d_block(f3, p + "level3_1")
+        self._mark("enc level3 done (before need 4)")
         need(4)
         f4 = self.pointconv(p + "level4", pc3, pc4, f3_4)
+        self._mark("enc end")
         return [xyz, pc1, pc2, pc3, pc4], [f0, f1, f2, f3, f4]
 
     def cross(self, xyz1, xyz2, points1, points2, knn1, knn2, pos, mlp, sorted_p3d, idx_c=None, bmap=None, shared=0):
@@ -472,8 +486,11 @@ class MoCoPCI(nn.Module):
         P = self._params()
         return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], 1e-6)
 
-    def ei_crossformer(self, prefix, x1, x2):
-        """EI_Crossformer.forward (mocopci.py:147-151): Injector(x1,x2) | Extractor(x2,x1) -> pj."""
+    def ei_crossformer(self, prefix, x1, x2, stacked=None):
+        """EI_Crossformer.forward (mocopci.py:147-151): Injector(x1,x2) | Extractor(x2,x1) -> pj.  stacked: the (2B,N,C) tensor
+        whose halves x1 and x2 are, when the caller has it (inference then takes the folded form below)."""
+        if self._live is None and stacked is not None and self.FOLD_EI:
+            return self.ei_crossformer_folded(prefix, stacked)
         P = self._params()
         i, e = prefix + ".injector", prefix + ".extractor"
         res1 = P[i + ".gamma"] * self.cross_attention(i + ".attn", self.layer_norm(x1, i + ".query_norm"),
@@ -482,6 +499,59 @@ class MoCoPCI(nn.Module):
         h = self.layer_norm(q, e + ".ffn_norm")
         res2 = self.lin(F.gelu(self.lin(h, e + ".ffn.fc1")), e + ".ffn.fc2")
         return F.linear(torch.cat([res1, res2], dim=-1), self.W(prefix + ".pj"))
+
+    def ei_crossformer_folded(self, prefix, f, heads=8):
+        """EI_Crossformer (mocopci.py:58-151) in inference, 26 launches folded to 9.  f (2B,N,C) = [x1; x2].
+        Everything affine is folded once into neighbouring weights (cached): the four LayerNorms in front of the q / kv projections
+        keep only their normalisation -- ONE call on the stacked batch -- and their scale / shift move into the projections, which
+        become one batched C -> 3C map per half ([q_i | kv_e] from x1, [q_e | kv_i] from x2); both attentions are ONE launch on the
+        stacked batch (queries of half h read keys / values of the other half: kv batch rotation); the Injector's proj, gamma and
+        its half of pj collapse into one matrix A, the Extractor's ffn.fc2 and its half of pj into Bm; ffn_norm keeps its
+        normalisation, fused with the residual sum in front of it, and its affine part moves into ffn.fc1:
+            O = attention(...)                      o_i = O[:B], o_e = O[B:]
+            h = normalise(x2 + o_e Wp_e^T + bp_e)   g = gelu(h W1'^T + b1')
+            out = o_i A^T + g Bm^T + c"""
+        be = ops.backend()
+        B2, N, C = f.shape
+        B = B2 // 2
+        P = self._params()
+
+        def fold():
+            i, e = prefix + ".injector", prefix + ".extractor"
+            ln = lambda n: (P[n + ".weight"], P[n + ".bias"])
+            zero = lambda w: torch.zeros(w.shape[0], device=w.device, dtype=w.dtype)
+            wb = lambda n: (self.W(n), self.Bv(n) if self.Bv(n) is not None else zero(self.W(n)))
+            (wq_i, bq_i), (wkv_i, bkv_i), (wp_i, bp_i) = wb(i + ".attn.q"), wb(i + ".attn.kv"), wb(i + ".attn.proj")
+            (wq_e, bq_e), (wkv_e, bkv_e), (wp_e, bp_e) = wb(e + ".attn.q"), wb(e + ".attn.kv"), wb(e + ".attn.proj")
+            (g_iq, b_iq), (g_if, b_if), (g_eq, b_eq), (g_ef, b_ef), (g_fn, b_fn) = (ln(i + ".query_norm"), ln(i + ".feat_norm"), ln(e + ".query_norm"),
+                                                                                     ln(e + ".feat_norm"), ln(e + ".ffn_norm"))
+            lin_ln = lambda w, b, g, sh: (w * g[None, :], w @ sh + b)        # Linear(LayerNorm affine(x)) as one affine map of the normalised x
+            (wa_q, ba_q), (wa_kv, ba_kv) = lin_ln(wq_i, bq_i, g_iq, b_iq), lin_ln(wkv_e, bkv_e, g_ef, b_ef)   # from x1: Injector query, Extractor feat
+            (wb_q, bb_q), (wb_kv, bb_kv) = lin_ln(wq_e, bq_e, g_eq, b_eq), lin_ln(wkv_i, bkv_i, g_if, b_if)   # from x2: Extractor query, Injector feat
+            w_in = torch.stack([torch.cat([wa_q, wa_kv], 0).t(), torch.cat([wb_q, wb_kv], 0).t()]).contiguous()        # (2, C, 3C)
+            b_in = torch.stack([torch.cat([ba_q, ba_kv]), torch.cat([bb_q, bb_kv])]).unsqueeze(1).contiguous()         # (2, 1, 3C)
+            (w1, b1), (w2, b2) = wb(e + ".ffn.fc1"), wb(e + ".ffn.fc2")
+            w1f, b1f = lin_ln(w1, b1, g_fn, b_fn)
+            wpj = self.W(prefix + ".pj")
+            wpj1, wpj2 = wpj[:, :C], wpj[:, C:]
+            gamma = P[i + ".gamma"]
+            a = (wpj1 * gamma[None, :]) @ wp_i                                                                         # (C, C): o_i -> out
+            bm = wpj2 @ w2                                                                                             # (C, H): g -> out
+            const = wpj1 @ (gamma * bp_i) + wpj2 @ b2
+            if self.Bv(prefix + ".pj") is not None:
+                const = const + self.Bv(prefix + ".pj")
+            return (w_in, b_in, wp_e.t().contiguous(), bp_e.contiguous(), w1f.t().contiguous(), b1f.contiguous(), a.t().contiguous(),
+                    bm.t().contiguous(), const.contiguous())
+        w_in, b_in, wpe_t, bp_e, w1_t, b1, a_t, bm_t, const = self.derived(("ei_fold", prefix), fold)
+        xh = be.add_layernorm(f, eps=1e-6)                                                    # (2B,N,C)
+        y = torch.baddbmm(b_in, xh.reshape(2, B * N, C), w_in).reshape(B2, N, 3 * C)        # [q | k | v] per half
+        o = be.attention_rot(y[..., :C], y[..., C:2 * C], y[..., 2 * C:], heads, B)           # (2B,N,C): [:B] Injector, [B:] Extractor
+        o_i, o_e = o[:B].reshape(B * N, C), o[B:].reshape(B * N, C)
+        h = be.add_layernorm(f[B:].reshape(B * N, C), o_e @ wpe_t, bp_e, eps=1e-6)
+        g = F.gelu(torch.addmm(b1, h, w1_t))
+        out = torch.addmm(const, o_i, a_t)
+        out.addmm_(g, bm_t)
+        return out.reshape(B, N, C)
 
     def folded_tail(self, fc2, mapping):
         """mapping(fc2(h)) as ONE affine map: W = Wmap Wfc2, b = Wmap bfc2 + bmap (cached).  Used where only the 3-channel
@@ -787,7 +857,19 @@ class MoCoPCI(nn.Module):
 
     # ---- decoder ------------------------------------------------------------------------
     def run_decoder(self, pcs, feats, B, train=False):
-        """MultiFrameEstimatier.forward (mocopci.py:821-1059).  pcs/feats hold both frames stacked on
+        """_decoder run to completion (no deferred tail)."""
+        gen = self._decoder(pcs, feats, B, train=train)
+        try:
+            next(gen)
+        except StopIteration as stop:
+            return stop.value
+        raise RuntimeError("decoder yielded without defer")
+
+    def _decoder(self, pcs, feats, B, train=False, defer=False):
+        """MultiFrameEstimatier.forward (mocopci.py:821-1059) as a generator: with defer=True it yields ONCE, right after the
+        refinement stage's furthest point sampling has been launched on its side stream -- the caller may enqueue other work on
+        this stream there (begin() / finish(): the next batch's encoder and decoder) -- and finishes when resumed; without defer it
+        never yields.  The result is the generator's return value.  pcs/feats hold both frames stacked on
         the batch axis (frame 1 = [:B], frame 2 = [B:]).  Returns out_lst: 3 x (B,N,3); with train=True
         (flows_lst_f, flows_lst_b, out_lst) as the reference does (mocopci.py:1056-1059), every (direction, frame) flow of every
         level being computed then (the training loss reads them all)."""
@@ -804,9 +886,11 @@ class MoCoPCI(nn.Module):
         # level-0 interpolation search were issued by the encoder as soon as their inputs existed (Early)
         # (level 3's own are needed right here, so they run inline)
         early = self._early
-        f3 = self.ei_crossformer(m + "ei3", feats[3][:B], feats[3][B:])
+        self._mark("dec start")
+        f3 = self.ei_crossformer(m + "ei3", feats[3][:B], feats[3][B:], stacked=feats[3])
         fus = [None, None, None, torch.cat([f3, f3], dim=0)]
 
+        self._mark("ei3 done")
         # l4 -> l3 (mocopci.py:842-845)
         f_l4_3 = self.conv1d_block(self.interp(pcs[3], pcs[4], feats[4], cache, "43"), m + "deconv4_3")
         c3 = torch.cat([feats[3], fus[3], f_l4_3], dim=-1)                         # (2B,256,576)
@@ -818,6 +902,7 @@ class MoCoPCI(nn.Module):
         new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
         # cross_block3, both directions at once (mocopci.py:853-856)
         xs = torch.stack([new3, sw(new3)], dim=1)                                  # (2B,2,N3,C)
+        self._mark("cross3 done")
         _, frame3s = self.cross_frame_att(m + "cross_block3", xs, feats=False)     # (2B,3,N3,3)
         f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
 
@@ -826,11 +911,13 @@ class MoCoPCI(nn.Module):
         # only (backward, frame 1) is dead at level 1; the same selection one level up measured no gain and is not made.)
         rows1 = None if train else [3 * i for i in range(B)] + [3 * i + 1 for i in range(B)] + [3 * (i + B) for i in range(B)]
 
+        self._mark("cross_block3 + deconv done")
         # l2 (mocopci.py:870-911): rows [:B] = forward direction, rows [B:] = backward direction
         ups = self.interp_flows(pcs[2], pcs[3], frame3s, cache, "32")
         C = feats[2].shape[-1]
         te = self.time_pair(B, C, dev)                                              # (2B,5,1,C)
         fus[2] = early.get(("fus", 2))
+        self._mark("got early fus2/cos2")
         frame2s, n1_2, n2_2 = self.multiframe_attention(m + "multi_frame_up_2", pcs[2], pcs_o[2], f_l3_2, sw(f_l3_2), feats[2], fus[2],
                                                         feats_o[2], fus[2], ups, te, idx_c12=early.get(("cos", 2)))  # (2B,3,N2,3)
         # l2 -> l1 (mocopci.py:920-927): the forward branch upsamples (feat1_new_f -> pc1, feat2_new_f -> pc2),
@@ -847,6 +934,7 @@ class MoCoPCI(nn.Module):
         # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).  Of the level-1 flows
         # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.
         fus[1] = early.get(("fus", 1))
+        self._mark("level2 done, got early fus1")
         frame1s = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
                                             feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=early.get(("cos", 1)))[0].contiguous()
         pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
@@ -866,6 +954,7 @@ class MoCoPCI(nn.Module):
         else:
             flow_src = frame1s                                                     # (3B,N1,3): the three flows read below
             up_flow = ops.backend().interp3_apply(flow_src, rep3(i3), rep3(w3))    # (3B,N,3)
+        self._mark("level1 done")
         warped = pc0 + up_flow
         # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022)
         wf = f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev)
@@ -883,13 +972,26 @@ class MoCoPCI(nn.Module):
             down, sel = self.fps_gather(warped, 2048, return_idx=True)
         wf = self.conv1d_block(wf, m + "rlevel0")
         idx_self = ops.backend().knn(warped, warped, 32)      # fusion's self search: independent of the refine branch
-        if side is not None:
+        if side is not None and defer:
+            # The sampling (a 1.2-1.4 ms latency chain on 24 CUs) is on its way; whatever the caller enqueues on this stream before
+            # resuming runs beside it, so neither the wait for it nor the 4x speculative PointConvD below is paid.
+            self._mark("refine FPS launched (tail deferred)")
+            yield
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(done)
+            be = ops.backend()
+            early.launch("i3_refine", lambda: be.interp3_search(warped, down), lane=1)
+            dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel))
+            shape = self.transformer_block(m + "shape1", dfeat, down)
+            upf = be.interp3_apply(shape, *early.get("i3_refine"))
+        elif side is not None:
             # same speculation as in the encoder: PointConvD of EVERY candidate centre and the Point-Transformer's four
             # per-point projections are computed while the sampling runs, the sampled rows are gathered afterwards
             be = ops.backend()
             t = m + "shape1"
             dfeat_all = self.pointconv(m + "level1", warped, warped, wf, idx=idx_self)
             qkv_all = self.qkv_projection(t, dfeat_all)                           # (3B,N,192)
+            self._mark("refine speculation done (before FPS wait)")
             main.wait_event(done)
             # the 3-NN search of the upsampling below needs only (warped, down): it runs beside the Point-Transformer kernel
             early.launch("i3_refine", lambda: be.interp3_search(warped, down), lane=1)
@@ -901,8 +1003,11 @@ class MoCoPCI(nn.Module):
             dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel))
             shape = self.transformer_block(m + "shape1", dfeat, down)
             upf = ops.backend().interp3(warped, down, shape)
+        self._mark("ptblock + interp done")
         refine = self.lin(self.lin(upf, m + "pred.0", slope=0.0), m + "pred.2")    # (3B,N,3): Linear, ReLU, Linear
+        self._mark("refine coords done")
         final = self.fusion(warped, refine, idx_self=idx_self, calls=3)
+        self._mark("fusion done")
         out_lst = [final[:B], final[B:2 * B], final[2 * B:]]
         if not train:
             return out_lst
@@ -947,6 +1052,57 @@ class MoCoPCI(nn.Module):
         return {"inputs": (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)), "stream": main.stream_id, "xyz": xyz, "laid_out": laid_out,
                 "pyramid": pyramid, "self_search": self_search, "scope": scope}
 
+    def begin(self, xyz1, xyz2, prefetched=None, then_prefetch=None, inputs_ready=None):
+        """First part of an inference forward, for a loop that keeps two batches in flight (software pipelining of consecutive
+        batches on ONE stream): everything up to and including the launch of the refinement stage's furthest point sampling
+        (encoder, decoder levels 3..1, warped clouds, their self search).  Returns a handle; finish(handle) enqueues the rest
+        (Point-Transformer refinement, fusion) and returns out_lst.  A serving loop calls begin(batch k+1) BEFORE finish(batch k):
+        the sampling of batch k -- a serial 1.2-1.4 ms chain that leaves 90 % of the chip idle, with nothing of batch k left to
+        run beside it -- then overlaps the encoder of batch k+1, and the PointConvD speculation that otherwise fills the wait (4x
+        the work) is not needed.  Same results as forward(); every batch's work is enqueued exactly once.  Arguments as forward()."""
+        B = xyz1.shape[0]
+        self._check_cache()
+        be = ops.backend()
+        h = prefetched
+        if h is None and inputs_ready is not None:
+            h = self.prefetch(xyz1, xyz2, inputs_ready)
+        scope = {} if h is None else h["scope"]
+        with torch.no_grad(), be.cloud_scope(scope):
+            xyz, pyramid, self_search = self._consume_prefetched(h, xyz1, xyz2)
+            early = self._early = Early(self, xyz.device)
+            pcs, feats = self.run_encoder(xyz, early, pyramid=pyramid, self_search=self_search)
+            if then_prefetch is not None:
+                self._next = self.prefetch(*then_prefetch)
+            gen = self._decoder(pcs, feats, B, defer=True)
+            try:
+                next(gen)
+                out = None
+            except StopIteration as stop:  # backends without streams never defer
+                gen, out = None, stop.value
+        return {"gen": gen, "scope": scope, "out": out}
+
+    def finish(self, pending):
+        """Second part of the forward begun with begin(): returns out_lst, 3 x (B,N,3)."""
+        if pending["gen"] is None:
+            return pending["out"]
+        with torch.no_grad(), ops.backend().cloud_scope(pending["scope"]):
+            try:
+                next(pending["gen"])
+            except StopIteration as stop:
+                pending["gen"] = None
+                return stop.value
+        raise RuntimeError("decoder yielded twice")
+
+    def _consume_prefetched(self, h, xyz1, xyz2):
+        """(xyz, pyramid, self_search) of a forward: from the prefetch handle (the stream waits for its layout), or laid out here."""
+        if h is None:
+            return torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous(), None, None
+        main = torch.cuda.current_stream(xyz1.device)
+        if h["inputs"] != (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)) or h["stream"] != main.stream_id:
+            raise RuntimeError("prefetched handle belongs to other inputs or another stream")
+        main.wait_event(h["laid_out"])
+        return h["xyz"], h["pyramid"], h["self_search"]
+
     def take_prefetched(self):
         """The handle forward(then_prefetch=...) produced (None if it did not); hands it over once."""
         h, self._next = self.__dict__.get("_next"), None
@@ -976,15 +1132,7 @@ class MoCoPCI(nn.Module):
             if h is None and inputs_ready is not None:
                 h = self.prefetch(xyz1, xyz2, inputs_ready)
             with torch.no_grad(), ops.backend().cloud_scope(None if h is None else h["scope"]):
-                pyramid = self_search = None
-                if h is not None:
-                    main = torch.cuda.current_stream(xyz1.device)
-                    if h["inputs"] != (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)) or h["stream"] != main.stream_id:
-                        raise RuntimeError("prefetched handle belongs to other inputs or another stream")
-                    xyz, pyramid, self_search = h["xyz"], h["pyramid"], h["self_search"]
-                    main.wait_event(h["laid_out"])
-                else:
-                    xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
+                xyz, pyramid, self_search = self._consume_prefetched(h, xyz1, xyz2)
                 self._early = Early(self, xyz.device)
                 pcs, feats = self.run_encoder(xyz, self._early, pyramid=pyramid, self_search=self_search)
                 if then_prefetch is not None:

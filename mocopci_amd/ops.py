@@ -388,6 +388,32 @@ class HipBackend:
               float(scale), out.data_ptr(), C)
         return out
 
+    def attention_rot(self, q, k, v, heads, kv_shift, scale=None):
+        """Attention over one stacked batch whose keys / values come from batch element (b + kv_shift) mod BF: q, k, v are
+        (BF,N,C) views with unit channel stride (e.g. column slices of one packed projection, read in place).  Inference only."""
+        BF, Nq, C = q.shape
+        Nk, hd = k.shape[1], C // heads
+        for t, n in ((q, Nq), (k, Nk), (v, Nk)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(0) == n * t.stride(1)):
+                raise RuntimeError("attention_rot: (BF,N,C) float32 CUDA views with unit channel stride and dense batches")
+        out = torch.empty((BF, Nq, C), dtype=torch.float32, device=q.device)
+        _call("mcp_attention", q, BF, Nq, Nk, heads, hd, q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), v.data_ptr(), v.stride(1),
+              int(kv_shift), float(hd ** -0.5 if scale is None else scale), out.data_ptr(), C)
+        return out
+
+    def add_layernorm(self, x, y=None, bias=None, eps=1e-6):
+        """(z - mean z) * rsqrt(var z + eps) over the last axis, z = x (+ y) (+ bias): one kernel (csrc/norm.hip).  Inference only."""
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        y2 = None if y is None else y.reshape(-1, C)
+        if x2.stride(1) != 1 or (y2 is not None and y2.stride(1) != 1):
+            raise RuntimeError("add_layernorm: unit channel stride")
+        out = torch.empty((x2.shape[0], C), dtype=torch.float32, device=x.device)
+        _call("mcp_add_layernorm", x, x2.shape[0], C, _lib.fptr(x2) if x2.is_contiguous() else x2.data_ptr(), x2.stride(0),
+              None if y2 is None else y2.data_ptr(), 0 if y2 is None else y2.stride(0), None if bias is None else _lib.fptr(bias), None, None,
+              float(eps), _lib.fptr(out), C)
+        return out.reshape(x.shape)
+
     # ---- per-point Linear with fused epilogue (csrc/linear.hip) ----
     @staticmethod
     def _pieces(xs):

@@ -17,6 +17,19 @@ class OracleBackend:
         import contextlib
         return contextlib.nullcontext()
 
+    def attention_rot(self, q, k, v, heads, kv_shift, scale=None):
+        BF, Nq, C = q.shape
+        hd = C // heads
+        k, v = torch.roll(k, -kv_shift, dims=0), torch.roll(v, -kv_shift, dims=0)  # batch b reads (b + kv_shift) mod BF
+        sp = lambda t: t.reshape(BF, t.shape[1], heads, hd).permute(0, 2, 1, 3)
+        o = torch.nn.functional.scaled_dot_product_attention(sp(q), sp(k), sp(v), scale=scale)
+        return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
+
+    def add_layernorm(self, x, y=None, bias=None, eps=1e-6):
+        z = x if y is None else x + y
+        z = z if bias is None else z + bias
+        return torch.nn.functional.layer_norm(z, (z.shape[-1],), None, None, eps)
+
     def fps(self, xyz, npoint):
         return orc.furthest_point_sample(xyz.detach(), npoint)
 

@@ -182,3 +182,32 @@ def test_prefetched_forwards_are_bit_identical_to_an_isolated_call():
     with pytest.raises(RuntimeError):
         net(y1, y2, prefetched=h)
     torch.cuda.synchronize()
+
+
+def test_two_batches_in_flight_give_the_isolated_results():
+    """begin(batch k+1) is enqueued BEFORE finish(batch k) (bench.py's serving loop): the refinement-stage sampling of batch k runs
+    beside batch k+1's encoder and the deferred tail takes the non-speculative PointConvD path.  Every batch must come out
+    exactly as an isolated forward() returns it."""
+    from mocopci_amd import synth
+    from tests import harness_checks as hc
+    net = hc.build_model(DEV)
+    x1, x2, _ = synth.make_batch(2, 8, 8192, device=DEV)
+    y1, y2, _ = synth.make_batch(2, 8, 8192, device=DEV, first_sample=8)
+    want = {0: net(x1, x2), 1: net(y1, y2)}
+    torch.cuda.synchronize()
+    order = [0, 1, 1, 0, 0]
+    batches = {0: (x1, x2), 1: (y1, y2)}
+    h = net.prefetch(*batches[order[0]])
+    pend, outs = None, []
+    for k, which in enumerate(order):
+        nxt = batches[order[k + 1]] if k + 1 < len(order) else None
+        cur = net.begin(*batches[which], prefetched=h, then_prefetch=nxt)
+        if pend is not None:
+            outs.append(net.finish(pend))
+        pend = cur
+        h = net.take_prefetched()
+    outs.append(net.finish(pend))
+    torch.cuda.synchronize()
+    assert len(outs) == len(order)
+    for k, (o, which) in enumerate(zip(outs, order)):
+        assert all(torch.equal(a, b) for a, b in zip(o, want[which])), f"pipelined batch {k} differs from its isolated forward"

@@ -7,10 +7,16 @@ net = MoCoPCI(); net.load_state_dict(synth.weights_by_name(net._spec)); net = ne
 x1, x2, _ = synth.make_batch(2, 8, 8192, device="cuda")
 ev = torch.cuda.Event(); ev.record()
 def run(n):
+    """the bench's serving loop: two batches in flight (begin / finish)"""
     h = net.prefetch(x1, x2, ev)
+    pend = None
     for i in range(n):
-        net(x1, x2, prefetched=h, then_prefetch=None if i == n - 1 else (x1, x2, ev))
+        cur = net.begin(x1, x2, prefetched=h, then_prefetch=None if i == n - 1 else (x1, x2, ev))
+        if pend is not None:
+            net.finish(pend)
+        pend = cur
         h = net.take_prefetched()
+    net.finish(pend)
 run(5)
 torch.cuda.synchronize()
 steps = 30
