@@ -107,7 +107,8 @@ def log_call_shapes(be, step):
     3-NN searches inside interp3 / interp3_search reach the timer through be.knn, so only be.knn records them; the fused
     small-level mcp_interp3 call (its own KNN launch inside the library) records here."""
     calls = {k: [] for k in FAMILIES}
-    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "ptblock_attention", "mlp2", "linear", "linear_narrow")
+    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "attention_rot", "ptblock_attention", "mlp2", "linear",
+             "linear_narrow")
     orig = {n: getattr(be, n) for n in names}
 
     def wrap(name, rec):
@@ -128,6 +129,7 @@ def log_call_shapes(be, step):
     be.cross_volume = wrap("cross_volume", lambda x1, x2, f1, *a, **k: calls["cross"].append((x1.shape[0], x1.shape[1], f1.shape[2])))
     be.pointconv_agg = wrap("pointconv_agg", lambda sx, nx, sp, *a: calls["pointconv"].append((nx.shape[0], nx.shape[1], sp.shape[2])))
     be.attention = wrap("attention", lambda q, kv, h, **kw: calls["attention"].append((q.shape[0], h, q.shape[1], kv.shape[1], q.shape[2] // h)))
+    be.attention_rot = wrap("attention_rot", lambda q, k, v, h, *a, **kw: calls["attention"].append((q.shape[0], h, q.shape[1], k.shape[1], q.shape[2] // h)))
     be.ptblock_attention = wrap("ptblock_attention", lambda xyz, q, *a: calls["ptblock"].append((q.shape[0], q.shape[1])))
     be.linear = wrap("linear", lambda xs, w, *a, **k: calls["linear"].append(((xs[0] if isinstance(xs, (tuple, list)) else xs).numel()
                                                                                // (xs[0] if isinstance(xs, (tuple, list)) else xs).shape[-1],
