@@ -43,7 +43,8 @@ NPOINTS = 8192
 B_PER_GPU = 8
 FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock", "mlp", "linear")
 HEADLINE = "fusion"  # the single kernel symbol with the most time on a step's critical (main) stream
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
+PMC_STAMP = os.path.join(ROOT, "profiles", "r03_pmc_sources.json")  # sha256 of every csrc file the profiled library was built from
 
 NAMES = {
     "fps": "fps_spatial_kernel / fps_resident_kernel (mcp_furthest_point_sampling_ws)",
@@ -75,6 +76,29 @@ NOTES = {
     "mlp": "2*rows*(C*H + H*C_out) flop of the fused Mlp_T / flow-head blocks on the split-bf16 path, weights streamed through LDS",
     "linear": "tall per-point Linear layers with fused activation / residual: bytes read + written, 4*rows*(K+n) (memory-bound by design)",
 }
+
+
+def kernel_sources_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile): tools/profile_round.sh stores it beside the counters it collects,
+    and a bench run whose sources differ flags the counters it quotes as stale instead of passing them off as this build's."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "mocopci_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) + [os.path.join(base, "Makefile")]):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
+def pmc_is_stale():
+    try:
+        return json.load(open(PMC_STAMP))["csrc_sha256"] != kernel_sources_digest()
+    except (OSError, KeyError, ValueError):
+        return True
+
+
+PMC_IS_STALE = pmc_is_stale()
 
 
 def algorithmic_work(kernel, calls):
@@ -170,7 +194,8 @@ def roofline_entries(timed, calls, steps, pmc):
         p = pmc.get(kname, {})
         if "hbm_bytes_per_launch" in p:
             e["traffic"] = p["hbm_bytes_per_launch"]
-            e["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build, read side doubled per the gfx950 rule)"
+            e["traffic_source"] = "profiles/r03_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build, read side doubled per the gfx950 rule)"
+            e["traffic_stale"] = PMC_IS_STALE
         for key in ("valu_busy_frac_of_chip", "mfma_busy_frac_of_chip", "mean_resident_waves_per_simd"):
             if key in p:
                 e[key] = p[key]

@@ -97,6 +97,7 @@ class MoCoPCI(nn.Module):
     attn_drop_rate = 0.05   # dropout on the softmax matrices of Multi_Frame_Att / Cross_Frame_Att
     drop_path_rate = 0.04   # stochastic depth of Multi_Frame_Att's two residual branches (Cross_Frame_Att: 0)
     BN_MOMENTUM = 0.1       # nn.BatchNorm default
+    PAIR_CFA = True         # inference: cross_block3 evaluated once for both decoder directions (it is symmetric in its two frames)
     FOLD_EI = True          # inference: EI cross-formers in their folded 9-launch form (A/B: tools/step_time.py net.FOLD_EI=0)
 
     def __init__(self):
@@ -407,6 +408,7 @@ class MoCoPCI(nn.Module):
         def branches(lvl, f):  # decoder work that needs nothing but this level's encoder features (both frames stacked)
             if early is None:
                 return
+            early.launch(("swap_f", lvl), lambda: swap(f), lane=lvl)   # the "other frame" arrangement the decoder reads
             early.launch(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:], stacked=f)), lane=lvl)
             early.launch(("cos", lvl), lambda: ops.backend().knn_cosine(f, swap(f), 16), lane=lvl)
 
@@ -416,6 +418,9 @@ class MoCoPCI(nn.Module):
         f1_2 = self.conv1d_block(f1, p + "level1_1")
         self._mark("enc level1 done")
         need(2)
+        if early is not None:  # the sampled clouds in the "other frame" arrangement (levels 1..3), off the main stream
+            early.launch(("swap_pc", 1), lambda: swap(pc1), lane=1)
+            early.launch(("swap_pc", 2), lambda: swap(pc2), lane=2)
         f2 = self.pointconv(p + "level2", pc1, pc2, f1_2)
         f2 = self.conv1d_block(f2, p + "level2_0")
         branches(2, f2)
@@ -424,6 +429,9 @@ class MoCoPCI(nn.Module):
         need(3)
         f3 = self.pointconv(p + "level3", pc2, pc3, f2_3)
         f3 = self.conv1d_block(f3, p + "level3_0")
+        if early is not None:
+            early.launch(("swap_pc", 3), lambda: swap(pc3), lane=3)
+            early.launch(("swap_f", 3), lambda: swap(f3), lane=3)
         f3_4 = self.conv1d_block(f3, p + "level3_1")
         self._mark("enc level3 done (before need 4)")
         need(4)
@@ -586,6 +594,31 @@ class MoCoPCI(nn.Module):
         xa = self.mlp_t(t, o, drop=drop)
         frames = self.lin(xa, prefix + ".mapping_xyz")
         return xa, frames                                                         # (B,3,N,C), (B,3,N,3)
+
+    def cross_frame_att_pair(self, prefix, new):
+        """cross_block3 on both decoder directions at once, inference, flows only.  new (2B,N,C): [:B] = feat1_new, [B:] = feat2_new.
+        The reference calls the block with the frame pair (feat1_new, feat2_new) for the forward direction and with the swapped
+        pair for the backward one (mocopci.py:853-856).  The block is symmetric in its two frames: its attention pairs frame f
+        with frame 1-f and SUMS over f (mocopci.py:619-621), so both calls compute A[b] + A[b+B] with A[i] = attention(q = y[i],
+        kv = y[(i+B) mod 2B]), y = norm1(new) -- the same sum, bit for bit (fp addition commutes).  So: one normalisation and one
+        projection of the 2B feature sets, ONE attention launch over 2B batch elements with the key / value batch rotated by B
+        (half the attention, projection and MLP work of running the block on the stacked (2B,2,N,C) pairs), and the three flow
+        frames serve both directions.  Returns (2B,3,N,3)."""
+        B2, N, C = new.shape
+        B = B2 // 2
+        a = prefix + ".attn_feats"
+        y = self.bn_eval(new, prefix + ".norm1", 1e-5)
+        def heads():  # head slot 0 is dropped and nothing after the attention mixes slots: project only slots 1..3
+            wq, bq, wkv, bkv = self.W(a + ".q"), self.Bv(a + ".q"), self.W(a + ".kv"), self.Bv(a + ".kv")
+            sl = lambda t: None if t is None else torch.cat([t[C:4 * C], t[5 * C:8 * C]], dim=0).contiguous()
+            return wq[C:].contiguous(), None if bq is None else bq[C:].contiguous(), sl(wkv), sl(bkv)
+        wq, bq, wkv, bkv = self.derived(("cfa_heads", prefix), heads)
+        q, kv = F.linear(y, wq, bq), F.linear(y, wkv, bkv)                        # (2B,N,3C), (2B,N,6C) = [k | v]
+        att = ops.backend().attention_rot(q, kv[..., :3 * C], kv[..., 3 * C:], 3, B, scale=C ** -0.5)     # (2B,N,3C)
+        o = (att[:B] + att[B:]).reshape(B, N, 3, C).transpose(1, 2)               # the sum over the two frames: (B,3,N,C)
+        o = self.lin(o, a + ".proj")
+        frames = self.mlp_t(prefix + ".trans_block_2", o, tail=prefix + ".mapping_xyz")   # (B,3,N,3)
+        return torch.cat([frames, frames], dim=0)
 
     def mlp_t(self, prefix, x, tail=None, res=None, bn=None, drop=0.0):
         """Mlp_T.forward (mocopci.py:1558-1565): fc1, depthwise 1x1 conv, PReLU, fc2 -- as ONE fused kernel (ops.mlp2).  Everything
@@ -877,15 +910,17 @@ class MoCoPCI(nn.Module):
         dev = pcs[0].device
         sw = lambda t: torch.cat([t[B:], t[:B]], dim=0)                            # swap the two frames
         # "other" frame, same order (levels 1..3 are the ones read)
-        pcs_o = [sw(p) if 1 <= i <= 3 else None for i, p in enumerate(pcs)]
-        feats_o = [sw(f) if 1 <= i <= 3 else None for i, f in enumerate(feats)]
+        early = self._early
+        # (the encoder issued these copies on side lanes as soon as their sources existed: six launches off the critical path)
+        got = lambda key, t: early.get(key) if key in early.items else sw(t)
+        pcs_o = [got(("swap_pc", i), p) if 1 <= i <= 3 else None for i, p in enumerate(pcs)]
+        feats_o = [got(("swap_f", i), f) if 1 <= i <= 3 else None for i, f in enumerate(feats)]
         cache = {}
 
         # EI cross-formers (mocopci.py:830-836): fusion features are shared by both frames
         # EI cross-formers (mocopci.py:830-836; fusion features shared by both frames), the feature-cosine searches and the
         # level-0 interpolation search were issued by the encoder as soon as their inputs existed (Early)
         # (level 3's own are needed right here, so they run inline)
-        early = self._early
         self._mark("dec start")
         f3 = self.ei_crossformer(m + "ei3", feats[3][:B], feats[3][B:], stacked=feats[3])
         fus = [None, None, None, torch.cat([f3, f3], dim=0)]
@@ -899,11 +934,19 @@ class MoCoPCI(nn.Module):
         x = m + "cross3"
         new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(c3_o, x + ".cross_t22"), feats[3],
                           feats_o[3], x + ".pos1", [x + ".mlp1.0"], False)
-        new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
+        if self._live is None:  # the two per-frame Linears as ONE batched product written straight into the stacked layout
+            wt, bt = self.derived(("cross3_t12", x), lambda: (torch.stack([self.W(x + ".cross_t1").t(), self.W(x + ".cross_t2").t()]).contiguous(),
+                                                               torch.stack([self.Bv(x + ".cross_t1"), self.Bv(x + ".cross_t2")]).unsqueeze(1).contiguous()))
+            new3 = torch.baddbmm(bt, new3.reshape(2, -1, new3.shape[-1]), wt).reshape(new3.shape[0], new3.shape[1], -1)
+        else:
+            new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
         # cross_block3, both directions at once (mocopci.py:853-856)
-        xs = torch.stack([new3, sw(new3)], dim=1)                                  # (2B,2,N3,C)
         self._mark("cross3 done")
-        _, frame3s = self.cross_frame_att(m + "cross_block3", xs, feats=False)     # (2B,3,N3,3)
+        if self._live is None and self.PAIR_CFA:
+            frame3s = self.cross_frame_att_pair(m + "cross_block3", new3)          # (2B,3,N3,3), both directions from one evaluation
+        else:
+            xs = torch.stack([new3, sw(new3)], dim=1)                              # (2B,2,N3,C)
+            _, frame3s = self.cross_frame_att(m + "cross_block3", xs, feats=False)  # (2B,3,N3,3)
         f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
 
         # Which level-1 flows are read: l0 (below) uses, of the 2B samples x 3 frames, the forward branch's frames 0,1 and
@@ -976,8 +1019,12 @@ class MoCoPCI(nn.Module):
             # The sampling (a 1.2-1.4 ms latency chain on 24 CUs) is on its way; whatever the caller enqueues on this stream before
             # resuming runs beside it, so neither the wait for it nor the 4x speculative PointConvD below is paid.
             self._mark("refine FPS launched (tail deferred)")
+            issued = torch.cuda.current_stream(dev)
             yield
             main = torch.cuda.current_stream(dev)
+            if main != issued:  # finish(..., tail_stream=...): the tail runs on another stream than the part that produced these
+                for t_ in (warped, wf, idx_self, down, sel):
+                    t_.record_stream(main)
             main.wait_event(done)
             be = ops.backend()
             early.launch("i3_refine", lambda: be.interp3_search(warped, down), lane=1)
@@ -1079,19 +1126,40 @@ class MoCoPCI(nn.Module):
                 out = None
             except StopIteration as stop:  # backends without streams never defer
                 gen, out = None, stop.value
-        return {"gen": gen, "scope": scope, "out": out}
+        ready = None
+        if gen is not None:
+            ready = torch.cuda.Event()
+            ready.record()
+        return {"gen": gen, "scope": scope, "out": out, "ready": ready}
 
-    def finish(self, pending):
-        """Second part of the forward begun with begin(): returns out_lst, 3 x (B,N,3)."""
+    def finish(self, pending, tail_stream=None):
+        """Second part of the forward begun with begin(): returns out_lst, 3 x (B,N,3).
+        tail_stream (optional): enqueue this part on that stream instead of the current one, behind the first part's last kernel; it
+        then runs CONCURRENTLY with whatever the current stream was given after begin() (the next batch's first part) -- the tail's
+        chip-filling kernels (32-NN search, fusion) beside the next encoder's launch-bound ones.  The current stream is made to wait
+        for the tail before it continues, so the returned tensors are safe to use on it."""
         if pending["gen"] is None:
             return pending["out"]
-        with torch.no_grad(), ops.backend().cloud_scope(pending["scope"]):
+        cur = torch.cuda.current_stream()
+        run_on = cur if tail_stream is None else tail_stream
+        if run_on != cur:
+            run_on.wait_event(pending["ready"])
+        with torch.no_grad(), ops.backend().cloud_scope(pending["scope"]), torch.cuda.stream(run_on):
             try:
                 next(pending["gen"])
             except StopIteration as stop:
                 pending["gen"] = None
-                return stop.value
-        raise RuntimeError("decoder yielded twice")
+                out = stop.value
+            else:
+                raise RuntimeError("decoder yielded twice")
+            if run_on != cur:
+                tail_done = torch.cuda.Event()
+                tail_done.record(run_on)
+        if run_on != cur:
+            cur.wait_event(tail_done)
+            for t in out:
+                t.record_stream(cur)
+        return out
 
     def _consume_prefetched(self, h, xyz1, xyz2):
         """(xyz, pyramid, self_search) of a forward: from the prefetch handle (the stream waits for its layout), or laid out here."""

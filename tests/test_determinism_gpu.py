@@ -184,7 +184,8 @@ def test_prefetched_forwards_are_bit_identical_to_an_isolated_call():
     torch.cuda.synchronize()
 
 
-def test_two_batches_in_flight_give_the_isolated_results():
+@pytest.mark.parametrize("tail_on_own_stream", [False, True])
+def test_two_batches_in_flight_give_the_isolated_results(tail_on_own_stream):
     """begin(batch k+1) is enqueued BEFORE finish(batch k) (bench.py's serving loop): the refinement-stage sampling of batch k runs
     beside batch k+1's encoder and the deferred tail takes the non-speculative PointConvD path.  Every batch must come out
     exactly as an isolated forward() returns it."""
@@ -196,6 +197,7 @@ def test_two_batches_in_flight_give_the_isolated_results():
     want = {0: net(x1, x2), 1: net(y1, y2)}
     torch.cuda.synchronize()
     order = [0, 1, 1, 0, 0]
+    tail = torch.cuda.Stream() if tail_on_own_stream else None   # finish() on a stream of its own, beside the next batch's first part
     batches = {0: (x1, x2), 1: (y1, y2)}
     h = net.prefetch(*batches[order[0]])
     pend, outs = None, []
@@ -203,10 +205,10 @@ def test_two_batches_in_flight_give_the_isolated_results():
         nxt = batches[order[k + 1]] if k + 1 < len(order) else None
         cur = net.begin(*batches[which], prefetched=h, then_prefetch=nxt)
         if pend is not None:
-            outs.append(net.finish(pend))
+            outs.append(net.finish(pend, tail_stream=tail))
         pend = cur
         h = net.take_prefetched()
-    outs.append(net.finish(pend))
+    outs.append(net.finish(pend, tail_stream=tail))
     torch.cuda.synchronize()
     assert len(outs) == len(order)
     for k, (o, which) in enumerate(zip(outs, order)):

@@ -30,7 +30,9 @@ FAMILIES = {  # name -> kernel-name substrings
     "fusion": ("fusion_kernel", "fusion_split_kernel"),
     "cross": ("cross_kernel",),
     "pointconv": ("pointconv_agg_kernel",),
-    "attention": ("attention_small_kernel", "attention_kernel"),
+    "attention": ("attention_small_kernel", "attention_wide_kernel", "attention_kernel"),
+    "attention_small": ("attention_small_kernel",),
+    "attention_wide": ("attention_wide_kernel",),
     "ptblock": ("ptblock_kernel",),
     "mlp": ("mlp2_kernel",),
     "linear": ("linear_kernel",),

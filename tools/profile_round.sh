@@ -19,7 +19,9 @@ echo "write done"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
     --output-format csv -d "$out/pmc_sq" -o s -- $B > "$out/pmc_sq.log" 2>&1
 echo "sq done"
+python3 -c "import json, bench; json.dump({'csrc_sha256': bench.kernel_sources_digest()}, open('$out/pmc_sources.json', 'w'))"
 python3 tools/pmc_counters.py "$out/pmc.json" $(find "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" -name '*counter_collection.csv') | tee "$out/pmc_summary.txt"
 # the raw per-dispatch CSVs are large: keep only the merged JSON and the stats
 python3 tools/step_timeline.py "$db" > "$out/step_timeline.txt" 2>&1 || true
+python3 tools/step_timeline.py "$db" --all > "$out/step_timeline_all.txt" 2>&1 || true
 rm -rf "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" "$out/trace"

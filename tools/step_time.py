@@ -21,6 +21,9 @@ x1, x2, _ = synth.make_batch(2, 8, 8192, device="cuda")
 ev = torch.cuda.Event(); ev.record()
 
 
+TAIL = torch.cuda.Stream() if "--tail-stream" in sys.argv else None
+
+
 def run(n):
     """the bench's serving loop: two batches in flight (begin / finish) unless --prefetch-only"""
     h = net.prefetch(x1, x2, ev)
@@ -32,11 +35,11 @@ def run(n):
         else:
             cur = net.begin(x1, x2, prefetched=h, then_prefetch=nxt)
             if pend is not None:
-                out = net.finish(pend)
+                out = net.finish(pend, tail_stream=TAIL)
             pend = cur
         h = net.take_prefetched()
     if pend is not None:
-        out = net.finish(pend)
+        out = net.finish(pend, tail_stream=TAIL)
     return out
 
 
