@@ -89,3 +89,55 @@ def weights_by_name(spec_or_state_dict):
             t = 0.05 * torch.randn(shape, generator=g)  # biases
         out[name] = t
     return out
+
+
+def weights_on_scan(spec_or_state_dict, flow_scale=0.1):
+    """A second deterministic weight set under which the predicted frames stay ON THE SCAN, so that Chamfer / EMD against the
+    ground truth are informative (with weights_by_name() the random `pred` head collapses every frame to a ~1-unit blob and
+    Chamfer-vs-GT is E|gt|^2 whatever the kernels do).  No checkpoint exists offline; this is weights_by_name() with a
+    hand-built coordinate-carrying path through the refinement branch (mocopci.py:1021-1053), everything else unchanged:
+      * a signed value v survives Conv1d + LeakyReLU(0.1) / ReLU layers as the channel pair (act(v), act(-v)):
+        act(v) - act(-v) = 1.1 v (LeakyReLU) or v (ReLU), so each Linear decodes the pair and re-encodes it;
+      * encoder.level0_lift writes (+xyz, -xyz) into channels 0..5; the three PointConv layers on the path get a constant WeightNet
+        (last conv: weight 0, bias 1), which turns their aggregation into a plain sum over the 32 neighbours, and a Linear that
+        picks the neighbourhood MEAN of the decoded coordinates; rlevel0 passes the pair on; the TransformerBlock keeps it in its
+        residual (fc2 rows zeroed); 3-NN upsampling is linear; `pred` decodes to xyz.
+    The refined cloud is then a smoothed copy of the warped input frame (local means over the 32-neighbourhoods the KNN / FPS /
+    grouping / interpolation kernels select -- a wrong neighbour list, sample or weight moves it), and the fusion stage averages
+    it once more.  The flow heads (mapping_xyz) are scaled by `flow_scale` so the motion branch stays small but live."""
+    w = weights_by_name(spec_or_state_dict)
+    pair = 1.0 / 1.1
+
+    def recode(t, bias, cols_plus, cols_minus, gain):
+        """rows 0..2 <- +gain*(in[cols_plus] - in[cols_minus]), rows 3..5 <- the negative; their biases 0"""
+        t[:6] = 0.0
+        for i in range(3):
+            t[i, cols_plus[i]], t[i, cols_minus[i]] = gain, -gain
+            t[i + 3, cols_plus[i]], t[i + 3, cols_minus[i]] = -gain, gain
+        bias[:6] = 0.0
+
+    lift = "encoder.level0_lift.composed_module.0"
+    w[lift + ".weight"][:6] = 0.0
+    for i in range(3):
+        w[lift + ".weight"][i, i, 0], w[lift + ".weight"][i + 3, i, 0] = 1.0, -1.0
+    w[lift + ".bias"][:6] = 0.0
+    for pc, d in (("encoder.level0", 32), ("multi_frame_inference.level1", 64)):
+        w[pc + ".weightnet.mlp_convs.2.weight"].zero_()
+        w[pc + ".weightnet.mlp_convs.2.bias"].fill_(1.0)
+        # aggregate index (3 + channel) * 8 + slot: slot 0 of the pair's feature channels, mean over the 32 neighbours
+        recode(w[pc + ".linear.weight"], w[pc + ".linear.bias"], [(3 + i) * 8 for i in range(3)], [(3 + i + 3) * 8 for i in range(3)], pair / 32.0)
+    r0 = "multi_frame_inference.rlevel0.composed_module.0"
+    recode(w[r0 + ".weight"][:, :, 0], w[r0 + ".bias"], [0, 1, 2], [3, 4, 5], pair)
+    sh = "multi_frame_inference.shape1"
+    w[sh + ".fc2.weight"][:6] = 0.0
+    w[sh + ".fc2.bias"][:6] = 0.0
+    recode(w["multi_frame_inference.pred.0.weight"], w["multi_frame_inference.pred.0.bias"], [0, 1, 2], [3, 4, 5], pair)
+    p2 = "multi_frame_inference.pred.2"
+    w[p2 + ".weight"].zero_()
+    w[p2 + ".bias"].zero_()
+    for i in range(3):
+        w[p2 + ".weight"][i, i], w[p2 + ".weight"][i, i + 3] = 1.0, -1.0
+    for name in w:
+        if ".mapping_xyz." in name:
+            w[name] *= flow_scale
+    return w

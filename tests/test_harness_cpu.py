@@ -101,3 +101,41 @@ def test_inference_cache_follows_in_place_parameter_updates(oracle_backend):
         want = fresh(x1, x2)
     assert any(not torch.equal(a, b) for a, b in zip(before, after))
     assert all(torch.equal(a, b) for a, b in zip(after, want))
+
+
+def test_forward_on_scan_weights_matches_reference_and_stays_on_the_scan(oracle_backend):
+    """The second weight set (synth.weights_on_scan): the reference's own forward is stored for it too, and under it the predicted
+    frames stay on the scan -- Chamfer-vs-GT is ~10 (N = 2048) instead of ~1000 = E|gt|^2 -- so the metric is informative."""
+    import numpy as np, os
+    out = hc.run_forward_check("cpu", "forward_scan_n2048", 8, 1, 2048, orc.chamfer, weights="scan")
+    g = np.load(os.path.join(hc.GOLD, "forward_scan_n2048.npz"))
+    assert float(g["chamfer"].max()) < 15.0
+
+
+def test_quality_metric_reacts_to_a_wrong_neighbour_search(oracle_backend):
+    """Under the on-scan weights Chamfer-vs-GT is a quality number: a kernel bug that hits 2 % of the points -- every 50th
+    32-neighbour list keeps its 16 nearest but takes its far half from a point half a cloud away -- moves it by more than 10 %
+    (measured 15 %), while it starts two orders of magnitude below E|gt|^2, where the stress weights sit."""
+    import torch
+    from mocopci_amd import ops, synth
+    be = ops.backend()
+    x1, x2, gt = synth.make_batch(8, 1, 1024)
+    real_knn = type(be).knn
+
+    def buggy(self, q, r, k, **kw):
+        idx = real_knn(self, q, r, k, **kw)
+        if k == 32 and not kw.get("return_dist"):
+            wrong = torch.cat([idx[..., :16], torch.roll(idx[..., :16], idx.shape[1] // 2, dims=1)], dim=-1)
+            idx = idx.clone()
+            idx[:, ::50] = wrong[:, ::50]
+        return idx
+    net = hc.build_model("cpu", "scan")
+    good = [float(orc.chamfer(o, g)) for o, g in zip(net(x1, x2), gt)]
+    type(be).knn = buggy
+    try:
+        bad = [float(orc.chamfer(o, g)) for o, g in zip(net(x1, x2), gt)]
+    finally:
+        type(be).knn = real_knn
+    e_gt2 = float((gt[0] ** 2).sum(-1).mean())
+    assert max(good) < 0.05 * e_gt2, (good, e_gt2)
+    assert min(abs(b - a) / a for a, b in zip(good, bad)) > 0.10, (good, bad)

@@ -27,6 +27,12 @@ def test_forward_baseline_point_count_on_gpu():
     hc.run_forward_check("cuda:0", "forward_c2_n8192", 2, 1, 8192, ops.backend().chamfer)
 
 
+def test_forward_on_scan_weights_matches_reference_on_gpu():
+    """The second weight set (synth.weights_on_scan, predictions stay on the scan): HIP path against the REFERENCE'S stored forward,
+    Chamfer-vs-GT within 1e-5 relative of the reference's -- here a quality number (~10 at N = 2048, not E|gt|^2)."""
+    hc.run_forward_check("cuda:0", "forward_scan_n2048", 8, 1, 2048, ops.backend().chamfer, weights="scan")
+
+
 def test_forward_full_size_runs_and_is_deterministic():
     # config 2 shape at B=2 (N=8192): two runs give identical output (no atomics on the forward path)
     from mocopci_amd import synth
