@@ -250,7 +250,7 @@ MCP_EXPORT int mcp_pointconv_agg(int b, int n, int s, int d, int k, const float 
     if (((uintptr_t)out) & 15) return MCP_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)b * s;
-    if ((d & 3) || (((uintptr_t)s_points) & 15)) return MCP_ERR_UNSUPPORTED;  // float4 gathers of 4 adjacent channels
+    const bool vec4 = !(d & 3) && !(((uintptr_t)s_points) & 15);  // float4 gathers of 4 adjacent channels need both
     mcp_prof_begin(MCP_KERNEL_POINTCONV, st);
     // points per workgroup so that PPB * d / 4 phase-2 items fill the 256 threads: 32 at d = 32, 16 at d = 64, 8 from d = 128 up;
     // one workgroup per PPB points (no persistent loop in practice): the dispatcher balances around whatever else holds CUs
@@ -258,8 +258,8 @@ MCP_EXPORT int mcp_pointconv_agg(int b, int n, int s, int d, int k, const float 
         const unsigned grid = (unsigned)min((total + ppb - 1) / ppb, 1LL << 20);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, total, n, s, d, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2, out);
     };
-    if (total <= 16384) {
-        const unsigned grid = (unsigned)((total + LPPB - 1) / LPPB);
+    if (total <= 16384 || !vec4) {
+        const unsigned grid = (unsigned)min((total + LPPB - 1) / LPPB, 1LL << 20);
         if (d >= 256 && total <= 8192)
             hipLaunchKernelGGL(pointconv_agg_lowlevel_kernel<1024>, dim3(grid), dim3(1024), 0, st, total, n, s, d, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2, out);
         else
