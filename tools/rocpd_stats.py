@@ -30,7 +30,11 @@ def main():
             for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
                 w.writerow([n, len(v), sum(v), round(sum(v) / len(v), 1), round(100 * sum(v) / tot, 3), min(v), max(v)])
     fus = [i for i, r in enumerate(rows) if "fusion_kernel" in r[0] or "fusion_split_kernel" in r[0]]
-    a, b = fus[-3], fus[-2]
+    # one steady-state step = the kernels between two consecutive fusion launches; the serving loop's pipeline fill / drain makes
+    # some windows short (two tails back to back), so take the window with the median kernel count
+    wins = sorted(range(len(fus) - 1), key=lambda i: fus[i + 1] - fus[i])
+    i = wins[len(wins) // 2]
+    a, b = fus[i], fus[i + 1]
     step = rows[a + 1:b + 1]
     lines = []
     wall = (step[-1][2] - step[0][1]) / 1e6

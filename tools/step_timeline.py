@@ -12,7 +12,9 @@ wx = [c for c in cols if "workgroup" in c.lower()]
 sel = ",".join(["name", "start", "end", "queue_id"] + gx[:3] + wx[:3])
 rows = db.execute(f"select {sel} from kernels order by start").fetchall()
 fus = [i for i, r in enumerate(rows) if "fusion_split_kernel" in r[0] or "fusion_kernel" in r[0]]
-step = rows[fus[-3] + 1:fus[-2] + 1]
+wins = sorted(range(len(fus) - 1), key=lambda i: fus[i + 1] - fus[i])   # median-sized window: a steady-state step
+i0 = wins[len(wins) // 2]
+step = rows[fus[i0] + 1:fus[i0 + 1] + 1]
 busy = {}
 for r in step:
     busy[r[3]] = busy.get(r[3], 0) + r[2] - r[1]
