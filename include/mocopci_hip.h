@@ -11,7 +11,9 @@
  *
  * Conventions (same contract as the reference extension):
  *   - all pointers are DEVICE pointers into contiguous fp32 / int32 buffers owned by
- *     the caller; the library never allocates, frees, or keeps state between calls;
+ *     the caller; the library never allocates or frees, reads no environment variable, and keeps no
+ *     state between calls except two per-process conveniences: the per-device "kernel attribute set"
+ *     flags (marked after the attribute call) and the opt-in launch timers of mcp_prof_*;
  *   - every call is enqueued asynchronously on `stream` (a hipStream_t passed as
  *     void*; NULL = the null stream) and returns without synchronising;
  *   - re-entrant and thread-safe; the device is the calling thread's current device;

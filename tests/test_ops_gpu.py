@@ -645,3 +645,37 @@ def test_linear_wide_outputs_run_as_column_blocks(rows, k, n):
     assert not be.linear_supported(x.to(DEV), n)
     got = be.linear(x.to(DEV), w.to(DEV), b.to(DEV), 0.25, None)
     torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("bf,n,heads,hd,shift", [(6, 300, 8, 8, 3), (4, 200, 8, 16, 2), (4, 256, 8, 32, 2), (4, 96, 3, 256, 2), (5, 130, 2, 64, 1)])
+def test_attention_with_rotated_key_value_batch_reads_packed_projections_in_place(bf, n, heads, hd, shift):
+    """mcp_attention: q / k / v are column slices of ONE packed projection (row stride 3C), batch element b of the queries attends
+    to keys / values of element (b + shift) mod BF -- what the folded EI cross-former and cross_block3 launch.  Against the
+    float64 dense formulation on the rolled tensors."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(bf * n + hd)
+    C = heads * hd
+    y = torch.randn(bf, n, 3 * C, generator=g)
+    want = OracleBackend().attention_rot(y[..., :C].double(), y[..., C:2 * C].double(), y[..., 2 * C:].double(), heads, shift).float()
+    yd = y.to(DEV)
+    got = ops.backend().attention_rot(yd[..., :C], yd[..., C:2 * C], yd[..., 2 * C:], heads, shift).cpu()
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+    # shift 0 on the same views = the plain entry points on contiguous copies
+    plain = ops.backend().attention(yd[..., :C].contiguous(), yd[..., C:].contiguous(), heads).cpu()
+    assert torch.equal(ops.backend().attention_rot(yd[..., :C], yd[..., C:2 * C], yd[..., 2 * C:], heads, 0).cpu(), plain)
+    with pytest.raises(RuntimeError):
+        ops.backend().attention_rot(yd[..., :C], yd[..., C:2 * C], yd[..., 2 * C:], heads, bf)   # shift out of range
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 64), (513, 128), (2048, 256), (7, 24), (300, 1000)])
+def test_add_layernorm_matches_torch(rows, c):
+    g = torch.Generator().manual_seed(rows + c)
+    x, y, b = torch.randn(rows, c, generator=g) * 3 + 1, torch.randn(rows, c, generator=g), torch.randn(c, generator=g)
+    be = ops.backend()
+    want = torch.nn.functional.layer_norm((x + y + b).double(), (c,), None, None, 1e-6).float()
+    torch.testing.assert_close(be.add_layernorm(x.to(DEV), y.to(DEV), b.to(DEV)).cpu(), want, rtol=2e-5, atol=2e-6)
+    want = torch.nn.functional.layer_norm(x.double(), (c,), None, None, 1e-6).float()
+    torch.testing.assert_close(be.add_layernorm(x.to(DEV)).cpu(), want, rtol=2e-5, atol=2e-6)
+    # a row-strided view (second half of a stacked batch) is read in place
+    xs = torch.randn(2, rows, c, generator=g).to(DEV)
+    torch.testing.assert_close(be.add_layernorm(xs[1]).cpu(), torch.nn.functional.layer_norm(xs[1].cpu(), (c,), None, None, 1e-6), rtol=2e-5, atol=2e-6)
