@@ -242,6 +242,15 @@ int mcp_add_layernorm(long long rows, int c, const float *x, long long x_stride,
                       const float *bias, const float *gamma, const float *beta, float eps, float *out, long long out_stride,
                       mcp_stream_t stream);
 
+/* Inputs of Multi_Frame_Att (mocopci.py:200-208, :551-557) in one pass: per output row r (a (sample, frame) pair),
+ *     x[r]  = fea[src_self[r]] + te_self[r]                    the flow embedding plus its time code
+ *     xn[r] = scale * x[r] + shift                             norm1 in eval mode (per-channel affine)
+ *     xr[r] = scale * (fea[src_partner[r]] + te_partner[r]) + shift     the attention partner, frame R-1-f of the flipped stack
+ * fea (members, n, c) holds the computed members in any order; src_* (rows) index it; te_* (rows, c); x / xn / xr (rows, n, c).
+ * c a multiple of 4, pointers 16-byte aligned. */
+int mcp_mfa_prepare(int rows, int n, int c, const float *fea, const int *src_self, const int *src_partner, const float *te_self,
+                    const float *te_partner, const float *scale, const float *shift, float *x, float *xn, float *xr, mcp_stream_t stream);
+
 /* chamfer_loss (models/utils.py:36-45 -> pytorch3d chamfer_distance defaults): per-point squared
  * nearest distance both ways.  x (B,N,3), y (B,M,3) -> dxy (B,N), dyx (B,M); the caller takes the means. */
 int mcp_chamfer_nn(int b, int n, int m, const float *x, const float *y, float *dxy, float *dyx, mcp_stream_t stream);

@@ -72,3 +72,48 @@ MCP_EXPORT int mcp_add_layernorm(long long rows, int c, const float *x, long lon
     else hipLaunchKernelGGL(add_layernorm_kernel<16>, grid, dim3(256), 0, s, rows, c, x, x_stride, y, y_stride, bias, gamma, beta, eps, out, out_stride);
     return mcp_launch_status();
 }
+
+// ---- inputs of Multi_Frame_Att in one pass (r3) ------------------------------------------------------------------------------
+// Multiframe_Attention (mocopci.py:200-208) stacks the flow embeddings of the three iterations with time codes, the block's norm1
+// (eval BatchNorm: a per-channel affine map) normalises them, and its attention pairs frame f with frame R-1-f of the flipped
+// stack.  In torch ops that was: zero-fill + index_put of the computed members, a permuted add of the time codes, the affine map,
+// a flip, and three row gathers when only some (sample, frame) rows are read -- eight launches over the same few MB.  Here, per
+// output row r: x = fea[src_self[r]] + te_self[r];  xn = scale * x + shift;  xr = scale * (fea[src_partner[r]] + te_partner[r]) + shift.
+namespace {
+__global__ __launch_bounds__(256) void mfa_prepare_kernel(long long total4, int nc4, int c4, const float4 *__restrict__ fea,
+                                                          const int *__restrict__ src_self, const int *__restrict__ src_partner,
+                                                          const float4 *__restrict__ te_self, const float4 *__restrict__ te_partner,
+                                                          const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+                                                          float4 *__restrict__ x, float4 *__restrict__ xn, float4 *__restrict__ xr) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e / nc4);
+        const int in = (int)(e - (long long)r * nc4), ch = in % c4;
+        const float4 sc = scale[ch], sh = shift[ch];
+        const float4 a = fea[(long long)src_self[r] * nc4 + in], ta = te_self[r * c4 + ch];
+        const float4 b = fea[(long long)src_partner[r] * nc4 + in], tb = te_partner[r * c4 + ch];
+        const float4 xv = make_float4(a.x + ta.x, a.y + ta.y, a.z + ta.z, a.w + ta.w);
+        const float4 pv = make_float4(b.x + tb.x, b.y + tb.y, b.z + tb.z, b.w + tb.w);
+        x[e] = xv;
+        xn[e] = make_float4(__builtin_fmaf(xv.x, sc.x, sh.x), __builtin_fmaf(xv.y, sc.y, sh.y), __builtin_fmaf(xv.z, sc.z, sh.z), __builtin_fmaf(xv.w, sc.w, sh.w));
+        xr[e] = make_float4(__builtin_fmaf(pv.x, sc.x, sh.x), __builtin_fmaf(pv.y, sc.y, sh.y), __builtin_fmaf(pv.z, sc.z, sh.z), __builtin_fmaf(pv.w, sc.w, sh.w));
+    }
+}
+}  // namespace
+
+MCP_EXPORT int mcp_mfa_prepare(int rows, int n, int c, const float *fea, const int *src_self, const int *src_partner, const float *te_self,
+                               const float *te_partner, const float *scale, const float *shift, float *x, float *xn, float *xr,
+                               mcp_stream_t stream) {
+    MCP_CHECK_ARGS(rows > 0 && n > 0 && c > 0 && fea && src_self && src_partner && te_self && te_partner && scale && shift && x && xn && xr);
+    if (c & 3) return MCP_ERR_UNSUPPORTED;
+    if ((((uintptr_t)fea) | ((uintptr_t)te_self) | ((uintptr_t)te_partner) | ((uintptr_t)scale) | ((uintptr_t)shift) | ((uintptr_t)x) | ((uintptr_t)xn) |
+         ((uintptr_t)xr)) & 15)
+        return MCP_ERR_BAD_ARG;
+    const int c4 = c / 4, nc4 = n * c4;
+    const long long total4 = (long long)rows * nc4;
+    const unsigned grid = (unsigned)min((total4 + 255) / 256, 1LL << 16);
+    hipLaunchKernelGGL(mfa_prepare_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, total4, nc4, c4, reinterpret_cast<const float4 *>(fea), src_self,
+                       src_partner, reinterpret_cast<const float4 *>(te_self), reinterpret_cast<const float4 *>(te_partner),
+                       reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(x),
+                       reinterpret_cast<float4 *>(xn), reinterpret_cast<float4 *>(xr));
+    return mcp_launch_status();
+}

@@ -665,10 +665,14 @@ class MoCoPCI(nn.Module):
         B, Fr, N, C = x.shape
         xn = self.bn_eval(x, prefix + ".norm1", 1e-5)
         xr = torch.flip(xn, dims=[1])
-        a = prefix + ".attn_feats"
         if rows is not None:  # only these (sample, frame) rows are wanted: queries, residual path and MLPs shrink with them
             x, xn, xr = (t.reshape(B * Fr, 1, N, C)[rows] for t in (x, xn, xr))
-            B, Fr = x.shape[0], 1
+        return self._mfa_core(prefix, x, xn, xr, heads, feats)
+
+    def _mfa_core(self, prefix, x, xn, xr, heads=8, feats=True):
+        """Multi_Frame_Att from its three inputs on: x (the stack + time codes), xn = norm1(x), xr = xn of the attention partners."""
+        B, Fr, N, C = x.shape
+        a = prefix + ".attn_feats"
         o = ops.backend().attention(self.lin(xn, a + ".q").reshape(B * Fr, N, C), self.lin(xr, a + ".kv").reshape(B * Fr, N, 2 * C),
                                     heads)                                         # (B*3,N,C)
         xn = self.lin(o.reshape(B, Fr, N, C), a + ".proj", res=xn)                 # xn + proj(attention), mocopci.py:559
@@ -775,6 +779,7 @@ class MoCoPCI(nn.Module):
         R = up_frames.shape[0] // B2                                               # up_frames: (R*B2,N,3), frame-major
         dev = pc1.device
         sel = None
+        rows_py = None if rows is None else list(rows)
         if rows is not None:
             # flow-embedding features are read only at the selected (sample, frame) rows and at the rows their attention
             # pairs with, (b, f) <-> (b, R-1-f); the other members of the 3 x (2B) batch are dropped
@@ -802,21 +807,44 @@ class MoCoPCI(nn.Module):
             n2a = self.cross(pc2w, pc1r, rep(t11_2), rep(t22_1), None, None, b + ".pos", bid_mlp, True, ic21)
             fea = self.cross(pc1r, pc2w, self.lin(n1a, fe + ".conv1"), self.lin(n2a, fe + ".conv2"), None, None, fe + ".pos", fe_mlp,
                              False, ic12)
-        if sel is not None:  # back to the 3 x (2B) layout; the dropped members are never read
-            full = fea.new_zeros((R * B2, *fea.shape[1:]))
-            full[sel] = fea
-            fea = full
-        fes = list(fea.reshape(R, B2, *fea.shape[1:]).unbind(0))
+        if self._live is not None:
+            if sel is not None:  # back to the 3 x (2B) layout; the dropped members are never read
+                full = fea.new_zeros((R * B2, *fea.shape[1:]))
+                full[sel] = fea
+                fea = full
+            fes = list(fea.reshape(R, B2, *fea.shape[1:]).unbind(0))
         n1, n2 = n1a[-B2:], n2a[-B2:]  # last iteration's (unused when rows are selected)
         # mocopci.py:203 stacks [feat1_new, fe_0..2, feat2_new] + time codes as 5 frames; Multi_Frame_Att keeps only the
         # inner three (see multi_frame_att), so the two outer frames are never built here
         if self._mode is not None:  # net.train(): the block's BatchNorms see all five frames of a sample (mocopci.py:200-208)
             _, frames = self.multi_frame_att_full(prefix + ".cross_block", torch.stack([n1, *fes, n2], dim=1) + time_enc)
             return frames, n1, n2
-        if self._live is None:  # one kernel: frame-major (R,B,N,C) read through a permuted view, written sample-major with the time codes
-            x = torch.add(fea.reshape(R, B2, *fea.shape[1:]).permute(1, 0, 2, 3), time_enc[:, 1:-1], out=fea.new_empty((B2, R, *fea.shape[1:])))
-        else:
-            x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                        # (B,3,N,C)
+        if self._live is None:
+            # ONE launch (ops.mfa_prepare) for what were eight: scatter of the computed members into the 3 x (2B) layout, time codes,
+            # norm1, the flip that pairs frame f with frame R-1-f, and the selection of the rows that are read downstream
+            cb = prefix + ".cross_block"
+            want = list(rows_py) if rows_py is not None else list(range(B2 * R))           # output rows r = b * R + f
+            store = {mem: i for i, mem in enumerate(need)} if sel is not None else None     # member f * B2 + b -> position in fea
+            def maps():
+                pos = lambda bb, f: (store[f * B2 + bb] if store is not None else f * B2 + bb)
+                bf = [divmod(r, R) for r in want]
+                ss = torch.tensor([pos(bb, f) for bb, f in bf], dtype=torch.int32, device=dev)
+                sp = torch.tensor([pos(bb, R - 1 - f) for bb, f in bf], dtype=torch.int32, device=dev)
+                te = time_enc[:, 1:-1, 0]                                                                     # (B2,R,C)
+                ts = torch.stack([te[bb, f] for bb, f in bf]).contiguous()
+                tp = torch.stack([te[bb, R - 1 - f] for bb, f in bf]).contiguous()
+                return ss, sp, ts, tp
+            ss, sp, ts, tp = self.derived(("mfa_maps", cb, B2, R, tuple(want), None if store is None else tuple(need)), maps)
+            P = self._params()
+            def fold():
+                scale = P[cb + ".norm1.weight"] * torch.rsqrt(P[cb + ".norm1.running_var"] + 1e-5)
+                return scale.contiguous(), (P[cb + ".norm1.bias"] - P[cb + ".norm1.running_mean"] * scale).contiguous()
+            scale, shift = self.derived(("bn", cb + ".norm1", 1e-5), fold)
+            x, xn, xr = ops.backend().mfa_prepare(fea.contiguous(), ss, sp, ts, tp, scale, shift)
+            shape = (len(want), 1) if rows_py is not None else (B2, R)
+            _, frames = self._mfa_core(cb, *(t.reshape(*shape, *t.shape[1:]) for t in (x, xn, xr)), feats=False)
+            return (frames[:, 0] if rows_py is not None else frames), n1a[-B2:], n2a[-B2:]
+        x = torch.stack(fes, dim=1) + time_enc[:, 1:-1]                            # (B,3,N,C): a training forward (eval graph)
         # (the block's third output, downsample(x_f), is never read by MultiFrameEstimatier.forward in inference)
         if rows is not None:  # only some (sample, frame) flows are read downstream
             _, frames = self.multi_frame_att(prefix + ".cross_block", x, rows=rows, feats=False)

@@ -414,6 +414,16 @@ class HipBackend:
               float(eps), _lib.fptr(out), C)
         return out.reshape(x.shape)
 
+    def mfa_prepare(self, fea, src_self, src_partner, te_self, te_partner, scale, shift):
+        """(x, xn, xr) of Multi_Frame_Att from the computed flow embeddings in one launch (csrc/norm.hip): fea (M,N,C), index lists
+        (R,) int32, time codes (R,C), norm1's eval scale / shift (C) -> three (R,N,C) tensors.  Inference only."""
+        M, N, C = fea.shape
+        R = src_self.shape[0]
+        x, xn, xr = (torch.empty((R, N, C), dtype=torch.float32, device=fea.device) for _ in range(3))
+        _call("mcp_mfa_prepare", fea, R, N, C, _lib.fptr(fea), _lib.iptr(src_self), _lib.iptr(src_partner), _lib.fptr(te_self), _lib.fptr(te_partner),
+              _lib.fptr(scale), _lib.fptr(shift), _lib.fptr(x), _lib.fptr(xn), _lib.fptr(xr))
+        return x, xn, xr
+
     # ---- per-point Linear with fused epilogue (csrc/linear.hip) ----
     @staticmethod
     def _pieces(xs):

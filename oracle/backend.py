@@ -30,6 +30,10 @@ class OracleBackend:
         z = z if bias is None else z + bias
         return torch.nn.functional.layer_norm(z, (z.shape[-1],), None, None, eps)
 
+    def mfa_prepare(self, fea, src_self, src_partner, te_self, te_partner, scale, shift):
+        x = fea[src_self.long()] + te_self[:, None, :]
+        return x, torch.addcmul(shift, x, scale), torch.addcmul(shift, fea[src_partner.long()] + te_partner[:, None, :], scale)
+
     def fps(self, xyz, npoint):
         return orc.furthest_point_sample(xyz.detach(), npoint)
 

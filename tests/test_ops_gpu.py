@@ -679,3 +679,19 @@ def test_add_layernorm_matches_torch(rows, c):
     # a row-strided view (second half of a stacked batch) is read in place
     xs = torch.randn(2, rows, c, generator=g).to(DEV)
     torch.testing.assert_close(be.add_layernorm(xs[1]).cpu(), torch.nn.functional.layer_norm(xs[1].cpu(), (c,), None, None, 1e-6), rtol=2e-5, atol=2e-6)
+
+
+def test_mfa_prepare_matches_torch():
+    """The three inputs of Multi_Frame_Att from a subset of computed members in one launch, against plain torch indexing."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(11)
+    M, N, C, R = 40, 300, 64, 24
+    fea = torch.randn(M, N, C, generator=g)
+    ss = torch.randint(0, M, (R,), generator=g, dtype=torch.int32)
+    sp = torch.randint(0, M, (R,), generator=g, dtype=torch.int32)
+    ts, tp, sc, sh = (torch.randn(R, C, generator=g), torch.randn(R, C, generator=g), torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g))
+    want = OracleBackend().mfa_prepare(fea, ss, sp, ts, tp, sc, sh)
+    got = ops.backend().mfa_prepare(*[t.to(DEV) for t in (fea, ss, sp, ts, tp, sc, sh)])
+    assert torch.equal(got[0].cpu(), want[0])
+    for a, b in zip(got[1:], want[1:]):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-6, atol=1e-6)
