@@ -552,7 +552,16 @@ class MoCoPCI(nn.Module):
                     bm.t().contiguous(), const.contiguous())
         w_in, b_in, wpe_t, bp_e, w1_t, b1, a_t, bm_t, const = self.derived(("ei_fold", prefix), fold)
         xh = be.add_layernorm(f, eps=1e-6)                                                    # (2B,N,C)
-        y = torch.baddbmm(b_in, xh.reshape(2, B * N, C), w_in).reshape(B2, N, 3 * C)        # [q | k | v] per half
+        # [q | k | v] per half: two GEMMs with the bias in their epilogue, written into the halves of one buffer (a batched product
+        # with a broadcast bias first materialises the bias at full size: a 35 us copy at level 1)
+        xh2 = xh.reshape(2, B * N, C)
+        if B * N >= 8192:
+            y = torch.empty((2, B * N, 3 * C), dtype=f.dtype, device=f.device)
+            torch.addmm(b_in[0, 0], xh2[0], w_in[0], out=y[0])
+            torch.addmm(b_in[1, 0], xh2[1], w_in[1], out=y[1])
+        else:  # few rows: the batched product fills the chip better than two small GEMMs in a row, and the bias copy is small
+            y = torch.baddbmm(b_in, xh2, w_in)
+        y = y.reshape(B2, N, 3 * C)
         o = be.attention_rot(y[..., :C], y[..., C:2 * C], y[..., 2 * C:], heads, B)           # (2B,N,C): [:B] Injector, [B:] Extractor
         o_i, o_e = o[:B].reshape(B * N, C), o[B:].reshape(B * N, C)
         h = be.add_layernorm(f[B:].reshape(B * N, C), o_e @ wpe_t, bp_e, eps=1e-6)
@@ -615,9 +624,11 @@ class MoCoPCI(nn.Module):
         wq, bq, wkv, bkv = self.derived(("cfa_heads", prefix), heads)
         q, kv = F.linear(y, wq, bq), F.linear(y, wkv, bkv)                        # (2B,N,3C), (2B,N,6C) = [k | v]
         att = ops.backend().attention_rot(q, kv[..., :3 * C], kv[..., 3 * C:], 3, B, scale=C ** -0.5)     # (2B,N,3C)
-        o = (att[:B] + att[B:]).reshape(B, N, 3, C).transpose(1, 2)               # the sum over the two frames: (B,3,N,C)
+        # the sum over the two frames; proj and the MLP act on the last axis only, so the (N, slot) order of the rows is kept as the
+        # attention wrote it and only the small (B,N,3,3) result is rearranged (transposing o first cost two copies of it)
+        o = (att[:B] + att[B:]).reshape(B, N, 3, C)
         o = self.lin(o, a + ".proj")
-        frames = self.mlp_t(prefix + ".trans_block_2", o, tail=prefix + ".mapping_xyz")   # (B,3,N,3)
+        frames = self.mlp_t(prefix + ".trans_block_2", o, tail=prefix + ".mapping_xyz").transpose(1, 2)   # (B,3,N,3)
         return torch.cat([frames, frames], dim=0)
 
     def mlp_t(self, prefix, x, tail=None, res=None, bn=None, drop=0.0):
