@@ -336,8 +336,15 @@ class MoCoPCI(nn.Module):
                 sel1 = sel if lvl == 1 else sel1
                 ready[lvl] = torch.cuda.Event()
                 ready[lvl].record(side)
-        for t in (*pcs[1:], sel1):  # allocated on the side stream, consumed on the main stream
+            # the sampled clouds in the decoder's "other frame" arrangement (levels 1..3): three small copies that ride along here,
+            # off the main stream and off the lanes the feature branches queue on
+            half = xyz.shape[0] // 2
+            swapped = {lvl: torch.cat([pcs[lvl][half:], pcs[lvl][:half]], dim=0) for lvl in (1, 2, 3)}
+            ready["swapped"] = torch.cuda.Event()
+            ready["swapped"].record(side)
+        for t in (*pcs[1:], sel1, *swapped.values()):  # allocated on the side stream, consumed on the main stream
             t.record_stream(main)
+        ready["swapped_clouds"] = swapped
         return pcs, sel1, ready
 
     def early_self_search(self, xyz, laid_out, main):
@@ -369,6 +376,9 @@ class MoCoPCI(nn.Module):
                 side.wait_stream(main)
                 pyramid = self.sample_pyramid(xyz, side)
             (_, pc1, pc2, pc3, pc4), sel1, ready = pyramid
+            if early is not None:
+                for lvl, t in ready["swapped_clouds"].items():
+                    early.items[("swap_pc", lvl)] = (t, ready["swapped"])
         else:
             pc1, sel1 = self.fps_gather(xyz, 2048, return_idx=True)
             pc2 = self.fps_gather(pc1, 512)
@@ -418,9 +428,6 @@ class MoCoPCI(nn.Module):
         f1_2 = self.conv1d_block(f1, p + "level1_1")
         self._mark("enc level1 done")
         need(2)
-        if early is not None:  # the sampled clouds in the "other frame" arrangement (levels 1..3), off the main stream
-            early.launch(("swap_pc", 1), lambda: swap(pc1), lane=1)
-            early.launch(("swap_pc", 2), lambda: swap(pc2), lane=2)
         f2 = self.pointconv(p + "level2", pc1, pc2, f1_2)
         f2 = self.conv1d_block(f2, p + "level2_0")
         branches(2, f2)
@@ -429,9 +436,6 @@ class MoCoPCI(nn.Module):
         need(3)
         f3 = self.pointconv(p + "level3", pc2, pc3, f2_3)
         f3 = self.conv1d_block(f3, p + "level3_0")
-        if early is not None:
-            early.launch(("swap_pc", 3), lambda: swap(pc3), lane=3)
-            early.launch(("swap_f", 3), lambda: swap(f3), lane=3)
         f3_4 = self.conv1d_block(f3, p + "level3_1")
         self._mark("enc level3 done (before need 4)")
         need(4)
@@ -950,10 +954,19 @@ class MoCoPCI(nn.Module):
         sw = lambda t: torch.cat([t[B:], t[:B]], dim=0)                            # swap the two frames
         # "other" frame, same order (levels 1..3 are the ones read)
         early = self._early
-        # (the encoder issued these copies on side lanes as soon as their sources existed: six launches off the critical path)
+        # (the encoder issued these copies off the main stream as soon as their sources existed -- the clouds with the sampling pyramid,
+        # the level-1 / 2 features on their lanes; level 3's features are needed right here and a lane result would make this stream
+        # wait for everything queued in front of it on the shared hardware queue, so that one copy stays on the main stream)
         got = lambda key, t: early.get(key) if key in early.items else sw(t)
-        pcs_o = [got(("swap_pc", i), p) if 1 <= i <= 3 else None for i, p in enumerate(pcs)]
-        feats_o = [got(("swap_f", i), f) if 1 <= i <= 3 else None for i, f in enumerate(feats)]
+        class _Other:  # fetched where a level is first read: a get() makes this stream wait for the lane that produced the copy
+            def __init__(self, kind, ts):
+                self.kind, self.ts, self.have = kind, ts, {}
+
+            def __getitem__(self, i):
+                if i not in self.have:
+                    self.have[i] = got((self.kind, i), self.ts[i])
+                return self.have[i]
+        pcs_o, feats_o = _Other("swap_pc", pcs), _Other("swap_f", feats)
         cache = {}
 
         # EI cross-formers (mocopci.py:830-836): fusion features are shared by both frames
