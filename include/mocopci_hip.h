@@ -61,6 +61,12 @@ size_t mcp_fps_workspace_bytes(int b, int n, int m);
 int mcp_furthest_point_sampling_ws(int b, int n, int m, const float *xyz, float *temp, int *idx, void *workspace,
                                    size_t workspace_bytes, mcp_stream_t stream);
 
+/* The same sampling for a fresh start (temp = 1e10 everywhere, which is what every caller of the reference passes:
+ * pointnet2_utils.py:24): the running distances live and die in the kernel, so no (b,n) buffer is filled or allocated.
+ * MCP_ERR_UNSUPPORTED where only the streaming kernel applies (n > 65536, or 16384 < n <= 65536 without workspace). */
+int mcp_furthest_point_sampling_fresh(int b, int n, int m, const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                                      mcp_stream_t stream);
+
 /* gather_points_wrapper(b,c,n,npoints,points,idx,out)      sampling.cpp:11-22, sampling_gpu.cu:8-44
  * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */
 int mcp_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx, float *out, mcp_stream_t stream);

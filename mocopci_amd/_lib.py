@@ -21,6 +21,7 @@ SIGNATURES = {
     "mcp_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
     "mcp_fps_workspace_bytes": [_i, _i, _i],
     "mcp_furthest_point_sampling_ws": [_i, _i, _i, _p, _p, _p, _p, ctypes.c_size_t, _p],
+    "mcp_furthest_point_sampling_fresh": [_i, _i, _i, _p, _p, _p, ctypes.c_size_t, _p],
     "mcp_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_group_points": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
@@ -91,10 +92,14 @@ def load():
     return _lib
 
 
+class Unsupported(RuntimeError):
+    """MCP_ERR_UNSUPPORTED: the compiled kernels do not cover this size (a RuntimeError, so existing handlers still see it)."""
+
+
 def check(rc):
     if rc != 0:
         msg = load().mcp_error_string(rc)
-        raise RuntimeError(f"libmocopci_hip: error {rc}: {msg.decode() if msg else '?'}")
+        raise (Unsupported if rc == 10002 else RuntimeError)(f"libmocopci_hip: error {rc}: {msg.decode() if msg else '?'}")
 
 
 def fptr(t):

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     xyz += (size_t)blockIdx.x * n * 3;
-    temp += (size_t)blockIdx.x * n;
+    if (temp) temp += (size_t)blockIdx.x * n;  // NULL: a fresh sampling -- every running distance starts at 1e10 and is not stored
     idxs += (size_t)blockIdx.x * m;
 
     float px[P], py[P], pz[P], pt[P];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
         px[j] = xyz[kk * 3 + 0];
         py[j] = xyz[kk * 3 + 1];
         pz[j] = xyz[kk * 3 + 2];
-        pt[j] = ok ? temp[kk] : -INFINITY;  // never selected, never stored
+        pt[j] = ok ? (temp ? temp[kk] : 1e10f) : -INFINITY;  // padding: never selected, never stored
         nsec[j] = ~fps_sec((uint32_t)kk, L);
     }
     if (LDS_XYZ) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int k = tid + T * p;
-        if (k < n) temp[k] = pt[p];
+        if (temp && k < n) temp[k] = pt[p];
     }
 }
 
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     xyz += (size_t)blockIdx.x * n * 3;
-    temp += (size_t)blockIdx.x * n;
+    if (temp) temp += (size_t)blockIdx.x * n;  // NULL: a fresh sampling -- every running distance starts at 1e10 and is not stored
     idxs += (size_t)blockIdx.x * m;
 
     // 1. bounding box of the cloud; a thread reads the P points it will key (blocked arrangement) once
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
         px[p] = xyz[src * 3 + 0];
         py[p] = xyz[src * 3 + 1];
         pz[p] = xyz[src * 3 + 2];
-        pt[p] = ok ? temp[src] : -INFINITY;  // never selected, never stored
+        pt[p] = ok ? (temp ? temp[src] : 1e10f) : -INFINITY;  // padding: never selected, never stored
         tag[p] = ((0x3FFFu - (((__brev((uint32_t)src & 1023u) >> 22) << 4) | ((uint32_t)src >> 10))) << 18) | ((uint32_t)src * 12u);
         if (ok) {
             lox = fminf(lox, px[p]); loy = fminf(loy, py[p]); loz = fminf(loz, pz[p]);
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        if (tid * P + p < n) temp[(tag[p] & 0x3FFFFu) / 12u] = pt[p];
+        if (temp && tid * P + p < n) temp[(tag[p] & 0x3FFFFu) / 12u] = pt[p];
     }
     if (lds_idx) {
         __syncthreads();
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int L, c
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     xyz += (size_t)blockIdx.x * n * 3;
-    temp += (size_t)blockIdx.x * n;
+    if (temp) temp += (size_t)blockIdx.x * n;  // NULL: a fresh sampling -- every running distance starts at 1e10 and is not stored
     idxs += (size_t)blockIdx.x * m;
     if (tid < 32) (&slots[0][0])[tid] = make_uint2(0u, 0u);
     if (tid == 0) idxs[0] = 0;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int np = tiles * TL_PTS;
     xyz += (size_t)blockIdx.x * n * 3;
-    temp += (size_t)blockIdx.x * n;
+    if (temp) temp += (size_t)blockIdx.x * n;  // NULL: a fresh sampling -- every running distance starts at 1e10 and is not stored
     idxs += (size_t)blockIdx.x * m;
     sx += (size_t)blockIdx.x * np;
     st += (size_t)blockIdx.x * np;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles
         const uint32_t pos = atomicAdd(&hist[cell_of(x, y, z)], 1u);
         const uint32_t tag = ((0xFFFFu - tl_rank((uint32_t)i)) << 10) | (pos >> 6);  // tie key above the tile id
         sx[pos] = make_float4(x, y, z, __uint_as_float(tag));
-        st[pos] = temp[i];
+        st[pos] = temp ? temp[i] : 1e10f;
     }
     for (int i = n + tid; i < np; i += TL_T) {  // padding of the last tile: never selected
         sx[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
@@ -664,7 +664,8 @@ __global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles
     }
     __syncthreads();
     // running distances back in the caller's order
-    for (int i = tid; i < n; i += TL_T) temp[tl_unrank(0xFFFFu - (__float_as_uint(sx[i].w) >> 10))] = st[i];
+    if (temp)
+        for (int i = tid; i < n; i += TL_T) temp[tl_unrank(0xFFFFu - (__float_as_uint(sx[i].w) >> 10))] = st[i];
     if (lds_idx) {
         for (int i = tid; i < m; i += TL_T) idxs[i] = sidx[i];
     }
@@ -832,7 +833,7 @@ int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, c
                 // the tiled kernel needs scratch for the sorted cloud; without it (or beyond its range): plain streaming, any N
                 rc = (tiled_range(n) && ws && ws_bytes >= tiled_workspace_bytes(b, n)) ? launch_tiled(b, n, m, xyz, temp, idx, ws, s)
                                                                                       : MCP_ERR_UNSUPPORTED;
-                if (rc == MCP_ERR_UNSUPPORTED) {
+                if (rc == MCP_ERR_UNSUPPORTED && temp) {  // (the streaming kernel keeps its running distances IN temp)
                     hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, s, n, m, L, xyz, temp, idx);
                     rc = mcp_launch_status();
                 }
@@ -865,4 +866,15 @@ MCP_EXPORT int mcp_furthest_point_sampling_ws(int b, int n, int m, const float *
     MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && temp && idx);
     if (m <= 0) return MCP_OK;
     return fps_dispatch(b, n, m, xyz, temp, idx, static_cast<char *>(workspace), workspace_bytes, (hipStream_t)stream);
+}
+
+/* A fresh sampling (every call of the caller graph is one): the running distances start at 1e10 inside the kernel and are not
+ * returned, so the caller neither fills nor allocates the (b,n) temp buffer of the reference interface.  Same indices as
+ * mcp_furthest_point_sampling_ws with temp = 1e10.  MCP_ERR_UNSUPPORTED where only the streaming kernel applies (n > 65536, or
+ * 16384 < n <= 65536 without workspace): use the temp interface there. */
+MCP_EXPORT int mcp_furthest_point_sampling_fresh(int b, int n, int m, const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                                                 mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && idx);
+    if (m <= 0) return MCP_OK;
+    return fps_dispatch(b, n, m, xyz, nullptr, idx, static_cast<char *>(workspace), workspace_bytes, (hipStream_t)stream);
 }

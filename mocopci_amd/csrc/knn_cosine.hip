@@ -30,13 +30,20 @@ __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >
 // through LDS with coalesced float4 traffic (rows are contiguous in memory), lane r < RW sums row r in channel order
 // from a padded (conflict-free) tile, and the scaled rows go back out coalesced.
 template <int C>
-__global__ __launch_bounds__(256) void normalize_rows_kernel(long long rows, const float *__restrict__ x, float *__restrict__ y) {
+__global__ __launch_bounds__(256) void normalize_rows_kernel(long long rows_a, const float *__restrict__ xa, float *__restrict__ ya,
+                                                             long long rows_b, const float *__restrict__ xb, float *__restrict__ yb) {
     constexpr int RW = C <= 64 ? 64 : (C == 128 ? 32 : 16), S = C + 1, V = RW * C / 4;  // float4s per tile
     __shared__ float tile[4][RW * S];
     __shared__ float den[4][RW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *t = tile[wave];
-    for (long long r0 = ((long long)blockIdx.x * 4 + wave) * RW; r0 < rows; r0 += (long long)gridDim.x * 4 * RW) {
+    // both feature sets of a search in ONE launch: tiles [0, ta) belong to (xa, ya), the rest to (xb, yb)
+    const long long ta = (rows_a + RW - 1) / RW, tb = (rows_b + RW - 1) / RW;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < ta + tb; g += (long long)gridDim.x * 4) {
+        const bool second = g >= ta;
+        const float *x = second ? xb : xa;
+        float *y = second ? yb : ya;
+        const long long rows = second ? rows_b : rows_a, r0 = (second ? g - ta : g) * RW;
         const int live = (int)min((long long)RW, rows - r0);
         const float4 *src = reinterpret_cast<const float4 *>(x + r0 * C);
         __builtin_amdgcn_wave_barrier();
@@ -69,10 +76,10 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(long long rows, con
 }
 
 template <int C>
-void launch_normalize(long long rows, const float *x, float *y, hipStream_t s) {
+void launch_normalize(long long rows_a, const float *xa, float *ya, long long rows_b, const float *xb, float *yb, hipStream_t s) {
     constexpr int RW = C <= 64 ? 64 : (C == 128 ? 32 : 16);
-    const long long blocks = (rows + 4 * RW - 1) / (4 * RW);
-    hipLaunchKernelGGL(normalize_rows_kernel<C>, dim3((unsigned)min(blocks, 4096LL)), dim3(256), 0, s, rows, x, y);
+    const long long tiles = (rows_a + RW - 1) / RW + (rows_b + RW - 1) / RW, blocks = (tiles + 3) / 4;
+    hipLaunchKernelGGL(normalize_rows_kernel<C>, dim3((unsigned)min(blocks, 4096LL)), dim3(256), 0, s, rows_a, xa, ya, rows_b, xb, yb);
 }
 
 template <int C>
@@ -190,9 +197,9 @@ MCP_EXPORT int mcp_knn_cosine(int b, int q, int n, int c, int k, const float *qf
     float *nq = workspace, *nr = workspace + (size_t)b * q * c;
     mcp_prof_begin(MCP_KERNEL_KNN_COSINE, s);
     const long long rq = (long long)b * q, rr = (long long)b * n;
-    if (c == 64) { launch_normalize<64>(rq, qfeat, nq, s); launch_normalize<64>(rr, rfeat, nr, s); }
-    else if (c == 128) { launch_normalize<128>(rq, qfeat, nq, s); launch_normalize<128>(rr, rfeat, nr, s); }
-    else { launch_normalize<256>(rq, qfeat, nq, s); launch_normalize<256>(rr, rfeat, nr, s); }
+    if (c == 64) launch_normalize<64>(rq, qfeat, nq, rr, rfeat, nr, s);
+    else if (c == 128) launch_normalize<128>(rq, qfeat, nq, rr, rfeat, nr, s);
+    else launch_normalize<256>(rq, qfeat, nq, rr, rfeat, nr, s);
     int rc = mcp_launch_status();
     if (rc == MCP_OK) {
         rc = c == 64    ? launch_cosine<64>(b, q, n, k, nq, nr, idx, dist, s)

@@ -420,7 +420,10 @@ class MoCoPCI(nn.Module):
                 return
             early.launch(("swap_f", lvl), lambda: swap(f), lane=lvl)   # the "other frame" arrangement the decoder reads
             early.launch(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:], stacked=f)), lane=lvl)
-            early.launch(("cos", lvl), lambda: ops.backend().knn_cosine(f, swap(f), 16), lane=lvl)
+            def cos():  # both directions of the feature-space search: the backward one is the forward one with its halves swapped
+                i12 = ops.backend().knn_cosine(f, swap(f), 16)
+                return i12, swap(i12)
+            early.launch(("cos", lvl), cos, lane=lvl)
 
         branches(1, f1)
         if early is not None:
@@ -786,7 +789,10 @@ class MoCoPCI(nn.Module):
         half = f1_0.shape[0] // 2
         if idx_c12 is None:
             idx_c12 = ops.backend().knn_cosine(f1_0, f2_0, 16)
-        idx_c21 = torch.cat([idx_c12[half:], idx_c12[:half]], dim=0)
+        if isinstance(idx_c12, (tuple, list)):  # the encoder's lane produced both arrangements
+            idx_c12, idx_c21 = idx_c12
+        else:
+            idx_c21 = torch.cat([idx_c12[half:], idx_c12[:half]], dim=0)
         # The loop over the 3 upsampled flows (mocopci.py:191-197) has no carried dependency -- the bid/fe layers always
         # see the original c_feat1/c_feat2 -- so the three iterations run as one batch of 3 x (2B); feat1_new/feat2_new
         # after the loop are those of the last iteration.
@@ -981,11 +987,17 @@ class MoCoPCI(nn.Module):
         # l4 -> l3 (mocopci.py:842-845)
         f_l4_3 = self.conv1d_block(self.interp(pcs[3], pcs[4], feats[4], cache, "43"), m + "deconv4_3")
         c3 = torch.cat([feats[3], fus[3], f_l4_3], dim=-1)                         # (2B,256,576)
-        c3_o = sw(c3)
         # cross3 (pointconv_util.py:783-791): rows [:B] give feat1_new, rows [B:] give feat2_new
         x = m + "cross3"
-        new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(c3_o, x + ".cross_t22"), feats[3],
-                          feats_o[3], x + ".pos1", [x + ".mlp1.0"], False)
+        if self._live is None:
+            # points2 = cross_t22 of the OTHER frame's concatenation: the kernel reads batch element b of the projection from element
+            # (b + B) mod 2B through its batch map instead of a swapped copy of the 576-wide input
+            swap_map = self.batch_map(tuple((i + B) % (2 * B) for i in range(2 * B)), dev)
+            new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(c3, x + ".cross_t22"), feats[3],
+                              feats_o[3], x + ".pos1", [x + ".mlp1.0"], False, bmap=swap_map, shared=2)
+        else:
+            new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(sw(c3), x + ".cross_t22"), feats[3],
+                              feats_o[3], x + ".pos1", [x + ".mlp1.0"], False)
         if self._live is None:  # the two per-frame Linears as ONE batched product written straight into the stacked layout
             wt, bt = self.derived(("cross3_t12", x), lambda: (torch.stack([self.W(x + ".cross_t1").t(), self.W(x + ".cross_t2").t()]).contiguous(),
                                                                torch.stack([self.Bv(x + ".cross_t1"), self.Bv(x + ".cross_t2")]).unsqueeze(1).contiguous()))

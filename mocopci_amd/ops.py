@@ -92,9 +92,15 @@ class HipBackend:
         xyz = xyz.detach()
         B, N, _ = xyz.shape
         out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
         need = _lib.load().mcp_fps_workspace_bytes(B, N, npoint)  # scratch for the tiled kernel (16384 < N <= 65536), else 0
         ws = torch.empty((need,), dtype=torch.uint8, device=xyz.device) if need else None
+        if N <= 65536:  # a fresh sampling: the running distances stay inside the kernel (no (B,N) buffer to fill)
+            try:
+                _call("mcp_furthest_point_sampling_fresh", xyz, B, N, npoint, _lib.fptr(xyz), _lib.iptr(out), ws.data_ptr() if need else None, need)
+                return out
+            except _lib.Unsupported:  # only the streaming kernel applies to this shape: it keeps its running distances in temp
+                pass
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
         _call("mcp_furthest_point_sampling_ws", xyz, B, N, npoint, _lib.fptr(xyz), _lib.fptr(temp), _lib.iptr(out),
               ws.data_ptr() if need else None, need)
         return out
