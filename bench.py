@@ -145,7 +145,7 @@ def log_call_shapes(be, step):
         if not (s_.shape[1] >= be.PRUNE_MIN_REFS and d.shape[1] >= be.PRUNE_MIN_QUERIES):
             calls["knn"].append((d.shape[0], d.shape[1], s_.shape[1], 3))
 
-    be.fps = wrap("fps", lambda xyz, m: calls["fps"].append((xyz.shape[0], xyz.shape[1], m)))
+    be.fps = wrap("fps", lambda xyz, m, **kw: calls["fps"].append((xyz.shape[0], xyz.shape[1], m)))
     be.knn = wrap("knn", lambda q, r, k, **kw: calls["knn"].append((q.shape[0], q.shape[1], r.shape[1], k)))
     be.interp3 = wrap("interp3", rec_interp3)
     be.knn_cosine = wrap("knn_cosine", lambda q, r, k, **kw: calls["knn_cosine"].append((q.shape[0], q.shape[1], r.shape[1], q.shape[2])))

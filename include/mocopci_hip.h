@@ -63,9 +63,11 @@ int mcp_furthest_point_sampling_ws(int b, int n, int m, const float *xyz, float 
 
 /* The same sampling for a fresh start (temp = 1e10 everywhere, which is what every caller of the reference passes:
  * pointnet2_utils.py:24): the running distances live and die in the kernel, so no (b,n) buffer is filled or allocated.
+ * sampled_xyz (b,m,3), optional (NULL to skip): the coordinates of the selected points -- the index_points_gather the callers
+ * run next (mocopci.py:1378-1379) -- written by the same launch.
  * MCP_ERR_UNSUPPORTED where only the streaming kernel applies (n > 65536, or 16384 < n <= 65536 without workspace). */
-int mcp_furthest_point_sampling_fresh(int b, int n, int m, const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                                      mcp_stream_t stream);
+int mcp_furthest_point_sampling_fresh(int b, int n, int m, const float *xyz, int *idx, float *sampled_xyz, void *workspace,
+                                      size_t workspace_bytes, mcp_stream_t stream);
 
 /* gather_points_wrapper(b,c,n,npoints,points,idx,out)      sampling.cpp:11-22, sampling_gpu.cu:8-44
  * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */

@@ -21,7 +21,7 @@ SIGNATURES = {
     "mcp_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
     "mcp_fps_workspace_bytes": [_i, _i, _i],
     "mcp_furthest_point_sampling_ws": [_i, _i, _i, _p, _p, _p, _p, ctypes.c_size_t, _p],
-    "mcp_furthest_point_sampling_fresh": [_i, _i, _i, _p, _p, _p, ctypes.c_size_t, _p],
+    "mcp_furthest_point_sampling_fresh": [_i, _i, _i, _p, _p, _p, _p, ctypes.c_size_t, _p],
     "mcp_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_group_points": [_i, _i, _i, _i, _i, _p, _p, _p, _p],

@@ -72,9 +72,22 @@ __device__ unsigned long long g_fps_diag[8];
 #define FPS_STAMP(slot)
 #endif
 
+// Optional last step of every sampling kernel: the coordinates of the selected points, (m,3) per batch element, so that the
+// furthest_point_sample + index_points_gather pair of the callers (mocopci.py:1378-1379) is one launch.  The indices were
+// written by this workgroup; the barrier (workgroup-scope release / acquire) makes them visible to all of its threads.
+template <int T>
+__device__ __forceinline__ void fps_emit_points(const float *__restrict__ xyz, const int *idxs, float *__restrict__ pts, int m, int tid) {
+    if (!pts) return;
+    __syncthreads();
+    for (int i = tid; i < m * 3; i += T) {
+        const int j = i / 3;
+        pts[i] = xyz[idxs[j] * 3 + (i - j * 3)];
+    }
+}
+
 template <int T, int P, int J, bool GENERIC, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, const float *__restrict__ xyz,
-                                                         float *__restrict__ temp, int *__restrict__ idxs) {
+                                                         float *__restrict__ temp, int *__restrict__ idxs, float *__restrict__ pts) {
     constexpr int W = T / 64;
     extern __shared__ float4 smem_f4[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_f4);  // [3] rotating max slots (+pad to 64 B)
@@ -87,6 +100,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
     xyz += (size_t)blockIdx.x * n * 3;
     if (temp) temp += (size_t)blockIdx.x * n;  // NULL: a fresh sampling -- every running distance starts at 1e10 and is not stored
     idxs += (size_t)blockIdx.x * m;
+    if (pts) pts += (size_t)blockIdx.x * m * 3;
 
     float px[P], py[P], pz[P], pt[P];
     uint32_t nsec[P];
@@ -201,6 +215,7 @@ __global__ __launch_bounds__(T) void fps_resident_kernel(int n, int m, int L, co
         int k = tid + T * p;
         if (temp && k < n) temp[k] = pt[p];
     }
+    fps_emit_points<T>(xyz, idxs, pts, m, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,7 +244,7 @@ using SpatialSort = rocprim::block_radix_sort<uint32_t, T, P>;
 
 template <int T, int P, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_idx, const float *__restrict__ xyz,
-                                                        float *__restrict__ temp, int *__restrict__ idxs) {
+                                                        float *__restrict__ temp, int *__restrict__ idxs, float *__restrict__ pts) {
     constexpr int W = T / 64;  // T * P >= n points are keyed and sorted (a power of two, <= 16384)
     extern __shared__ float4 smem_f4[];
     // header (512 B): [0,24) rotating max slots, [64,448) bbox reduction scratch, [448,472) cloud bbox
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
     xyz += (size_t)blockIdx.x * n * 3;
     if (temp) temp += (size_t)blockIdx.x * n;  // NULL: a fresh sampling -- every running distance starts at 1e10 and is not stored
     idxs += (size_t)blockIdx.x * m;
+    if (pts) pts += (size_t)blockIdx.x * m * 3;
 
     // 1. bounding box of the cloud; a thread reads the P points it will key (blocked arrangement) once
     uint32_t keys[P];
@@ -401,18 +417,20 @@ __global__ __launch_bounds__(T) void fps_spatial_kernel(int n, int m, int lds_id
         __syncthreads();
         for (int i = tid; i < m; i += T) idxs[i] = sidx[i] / 12;
     }
+    fps_emit_points<T>(xyz, idxs, pts, m, tid);
 }
 
 // Large-N fallback (N > 16 points per lane at 1024 threads): temp stays in global memory,
 // xyz is re-read from L2 each iteration, same (ord, ~sec) reduction.  Correct for any N.
 __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int L, const float *__restrict__ xyz,
-                                                          float *__restrict__ temp, int *__restrict__ idxs) {
+                                                          float *__restrict__ temp, int *__restrict__ idxs, float *__restrict__ pts) {
     __shared__ uint2 slots[2][16];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     xyz += (size_t)blockIdx.x * n * 3;
     if (temp) temp += (size_t)blockIdx.x * n;  // NULL: a fresh sampling -- every running distance starts at 1e10 and is not stored
     idxs += (size_t)blockIdx.x * m;
+    if (pts) pts += (size_t)blockIdx.x * m * 3;
     if (tid < 32) (&slots[0][0])[tid] = make_uint2(0u, 0u);
     if (tid == 0) idxs[0] = 0;
     __syncthreads();
@@ -441,6 +459,7 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int L, c
         old = (int)fps_unsec(~wlo, L);
         if (tid == 0) idxs[j] = old;
     }
+    fps_emit_points<1024>(xyz, idxs, pts, m, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,8 +486,8 @@ __device__ __forceinline__ uint32_t tl_rank(uint32_t k) { return ((__brev(k & 10
 __device__ __forceinline__ uint32_t tl_unrank(uint32_t r) { return (__brev(r >> 6) >> 22) | ((r & 63u) << 10); }
 
 __global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles, int lds_idx, const float *__restrict__ xyz,
-                                                         float *__restrict__ temp, int *__restrict__ idxs, float4 *__restrict__ sx,
-                                                         float *__restrict__ st) {
+                                                         float *__restrict__ temp, int *__restrict__ idxs, float *__restrict__ pts,
+                                                         float4 *__restrict__ sx, float *__restrict__ st) {
     extern __shared__ float4 smem_f4[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_f4);                  // [3]
     float(*red)[16] = reinterpret_cast<float(*)[16]>(reinterpret_cast<float *>(smem_f4) + 16);   // [6][16]
@@ -484,6 +503,7 @@ __global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles
     xyz += (size_t)blockIdx.x * n * 3;
     if (temp) temp += (size_t)blockIdx.x * n;  // NULL: a fresh sampling -- every running distance starts at 1e10 and is not stored
     idxs += (size_t)blockIdx.x * m;
+    if (pts) pts += (size_t)blockIdx.x * m * 3;
     sx += (size_t)blockIdx.x * np;
     st += (size_t)blockIdx.x * np;
 
@@ -669,6 +689,7 @@ __global__ __launch_bounds__(TL_T) void fps_tiled_kernel(int n, int m, int tiles
     if (lds_idx) {
         for (int i = tid; i < m; i += TL_T) idxs[i] = sidx[i];
     }
+    fps_emit_points<TL_T>(xyz, idxs, pts, m, tid);
 }
 
 size_t tiled_workspace_bytes(int b, int n) {
@@ -677,7 +698,7 @@ size_t tiled_workspace_bytes(int b, int n) {
 }
 
 // ws: caller-provided scratch of at least tiled_workspace_bytes(b, n) bytes (the library never allocates)
-int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, char *ws, hipStream_t s) {
+int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, float *pts, char *ws, hipStream_t s) {
     const int tiles = (n + TL_PTS - 1) / TL_PTS;
     const size_t np = (size_t)tiles * TL_PTS;
     size_t lds = 512 + (size_t)TL_CELLS * 4 + sizeof(typename TiledScan::storage_type);
@@ -695,7 +716,7 @@ int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_once.done();
     }
-    hipLaunchKernelGGL(fps_tiled_kernel, dim3(b), dim3(TL_T), lds, s, n, m, tiles, lds_idx, xyz, temp, idx, sx, st);
+    hipLaunchKernelGGL(fps_tiled_kernel, dim3(b), dim3(TL_T), lds, s, n, m, tiles, lds_idx, xyz, temp, idx, pts, sx, st);
     return mcp_launch_status();
 }
 
@@ -708,7 +729,7 @@ int ref_block_log2(int n) {
 }
 
 template <int T, int P, int J, bool GENERIC>
-int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
+int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, float *pts, hipStream_t s) {
     const size_t slot_bytes = 64;
     const size_t xyz_bytes = (size_t)n * 3 * sizeof(float);
     const size_t idx_bytes = (size_t)(m > 0 ? m : 1) * sizeof(int);  // the selected indices are buffered in LDS (m <= n)
@@ -719,7 +740,7 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_once.done();
         }
-        hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + xyz_bytes + idx_bytes, s, n, m, L, xyz, temp, idx);
+        hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + xyz_bytes + idx_bytes, s, n, m, L, xyz, temp, idx, pts);
     } else {
         if (slot_bytes + idx_bytes > 150 * 1024) return MCP_ERR_UNSUPPORTED;
         auto kern = fps_resident_kernel<T, P, J, GENERIC, false>;
@@ -728,13 +749,13 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_once2.done();
         }
-        hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + idx_bytes, s, n, m, L, xyz, temp, idx);
+        hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + idx_bytes, s, n, m, L, xyz, temp, idx, pts);
     }
     return mcp_launch_status();
 }
 
 template <int T, int P>
-int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
+int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, float *pts, hipStream_t s) {
     const size_t head = 512, key_bytes = sizeof(typename SpatialSort<T, P>::storage_type), xyz_bytes = (size_t)n * 3 * sizeof(float);
     const bool lds_xyz = head + xyz_bytes <= 160 * 1024;
     size_t lds = head + (lds_xyz && xyz_bytes > key_bytes ? xyz_bytes : key_bytes);
@@ -752,8 +773,8 @@ int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, in
         attr_once.done();
     }
     (void)L;  // n >= 1024: the reference block size is 1024 (asserted by the caller)
-    if (lds_xyz) hipLaunchKernelGGL((fps_spatial_kernel<T, P, true>), dim3(b), dim3(T), lds, s, n, m, lds_idx, xyz, temp, idx);
-    else hipLaunchKernelGGL((fps_spatial_kernel<T, P, false>), dim3(b), dim3(T), lds, s, n, m, lds_idx, xyz, temp, idx);
+    if (lds_xyz) hipLaunchKernelGGL((fps_spatial_kernel<T, P, true>), dim3(b), dim3(T), lds, s, n, m, lds_idx, xyz, temp, idx, pts);
+    else hipLaunchKernelGGL((fps_spatial_kernel<T, P, false>), dim3(b), dim3(T), lds, s, n, m, lds_idx, xyz, temp, idx, pts);
     return mcp_launch_status();
 }
 
@@ -769,30 +790,30 @@ int env_int(const char *name, int dflt) {
 }
 
 // workgroup size for the spatial kernel by sort size (tuning override: MCP_FPS_T)
-int launch_spatial_any(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, hipStream_t s) {
+int launch_spatial_any(int b, int n, int m, int L, const float *xyz, float *temp, int *idx, float *pts, hipStream_t s) {
     static const int force_t = env_int("MCP_FPS_T", 0);
     int ns = 2048;
     while (ns < n) ns <<= 1;
     const int t = force_t ? force_t : 1024;
     switch (ns / t) {
-        case 2: if (t == 1024) return launch_spatial<1024, 2>(b, n, m, L, xyz, temp, idx, s); break;
+        case 2: if (t == 1024) return launch_spatial<1024, 2>(b, n, m, L, xyz, temp, idx, pts, s); break;
         case 4:
-            if (t == 1024) return launch_spatial<1024, 4>(b, n, m, L, xyz, temp, idx, s);
-            if (t == 512) return launch_spatial<512, 4>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 1024) return launch_spatial<1024, 4>(b, n, m, L, xyz, temp, idx, pts, s);
+            if (t == 512) return launch_spatial<512, 4>(b, n, m, L, xyz, temp, idx, pts, s);
             break;
         case 8:
-            if (t == 1024) return launch_spatial<1024, 8>(b, n, m, L, xyz, temp, idx, s);
-            if (t == 512) return launch_spatial<512, 8>(b, n, m, L, xyz, temp, idx, s);
-            if (t == 256) return launch_spatial<256, 8>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 1024) return launch_spatial<1024, 8>(b, n, m, L, xyz, temp, idx, pts, s);
+            if (t == 512) return launch_spatial<512, 8>(b, n, m, L, xyz, temp, idx, pts, s);
+            if (t == 256) return launch_spatial<256, 8>(b, n, m, L, xyz, temp, idx, pts, s);
             break;
         case 16:
-            if (t == 1024) return launch_spatial<1024, 16>(b, n, m, L, xyz, temp, idx, s);
-            if (t == 512) return launch_spatial<512, 16>(b, n, m, L, xyz, temp, idx, s);
-            if (t == 256) return launch_spatial<256, 16>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 1024) return launch_spatial<1024, 16>(b, n, m, L, xyz, temp, idx, pts, s);
+            if (t == 512) return launch_spatial<512, 16>(b, n, m, L, xyz, temp, idx, pts, s);
+            if (t == 256) return launch_spatial<256, 16>(b, n, m, L, xyz, temp, idx, pts, s);
             break;
         case 32:
-            if (t == 512) return launch_spatial<512, 32>(b, n, m, L, xyz, temp, idx, s);
-            if (t == 256) return launch_spatial<256, 32>(b, n, m, L, xyz, temp, idx, s);
+            if (t == 512) return launch_spatial<512, 32>(b, n, m, L, xyz, temp, idx, pts, s);
+            if (t == 256) return launch_spatial<256, 32>(b, n, m, L, xyz, temp, idx, pts, s);
             break;
     }
     return MCP_ERR_UNSUPPORTED;
@@ -812,38 +833,38 @@ extern "C" __attribute__((visibility("default"))) int mcp_fps_diag_read(unsigned
 namespace {
 bool tiled_range(int n) { return n > 16384 && n <= 65536; }
 
-int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, char *ws, size_t ws_bytes, hipStream_t s) {
+int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, float *pts, char *ws, size_t ws_bytes, hipStream_t s) {
     const int L = ref_block_log2(n);
     const int bs = 1 << L;
     int rc;
     mcp_prof_begin(MCP_KERNEL_FPS, s);
     static const int spatial_min = env_int("MCP_FPS_SPATIAL_MIN", 1024);
     if (n >= spatial_min && L == 10 && n <= 16384 && m > 1) {
-        rc = launch_spatial_any(b, n, m, L, xyz, temp, idx, s);
+        rc = launch_spatial_any(b, n, m, L, xyz, temp, idx, pts, s);
     } else if (bs >= 64) {
         const int P = (n + bs - 1) / bs;
         if (bs == 1024) {
             // half-size workgroups (J = 1) from 4 points per reference thread up: fewer waves in the reduction
-            if (P <= 1) rc = launch_resident<1024, 1, 0, false>(b, n, m, L, xyz, temp, idx, s);
-            else if (P <= 2) rc = launch_resident<1024, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
-            else if (P <= 4) rc = launch_resident<MCP_FPS_T4, MCP_FPS_P4, MCP_FPS_J4, false>(b, n, m, L, xyz, temp, idx, s);
-            else if (P <= 8) rc = launch_resident<MCP_FPS_T8, MCP_FPS_P8, MCP_FPS_J8, false>(b, n, m, L, xyz, temp, idx, s);
-            else if (P <= 16) rc = launch_resident<1024, 16, 0, false>(b, n, m, L, xyz, temp, idx, s);
+            if (P <= 1) rc = launch_resident<1024, 1, 0, false>(b, n, m, L, xyz, temp, idx, pts, s);
+            else if (P <= 2) rc = launch_resident<1024, 2, 0, false>(b, n, m, L, xyz, temp, idx, pts, s);
+            else if (P <= 4) rc = launch_resident<MCP_FPS_T4, MCP_FPS_P4, MCP_FPS_J4, false>(b, n, m, L, xyz, temp, idx, pts, s);
+            else if (P <= 8) rc = launch_resident<MCP_FPS_T8, MCP_FPS_P8, MCP_FPS_J8, false>(b, n, m, L, xyz, temp, idx, pts, s);
+            else if (P <= 16) rc = launch_resident<1024, 16, 0, false>(b, n, m, L, xyz, temp, idx, pts, s);
             else {
                 // the tiled kernel needs scratch for the sorted cloud; without it (or beyond its range): plain streaming, any N
-                rc = (tiled_range(n) && ws && ws_bytes >= tiled_workspace_bytes(b, n)) ? launch_tiled(b, n, m, xyz, temp, idx, ws, s)
+                rc = (tiled_range(n) && ws && ws_bytes >= tiled_workspace_bytes(b, n)) ? launch_tiled(b, n, m, xyz, temp, idx, pts, ws, s)
                                                                                       : MCP_ERR_UNSUPPORTED;
                 if (rc == MCP_ERR_UNSUPPORTED && temp) {  // (the streaming kernel keeps its running distances IN temp)
-                    hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, s, n, m, L, xyz, temp, idx);
+                    hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, s, n, m, L, xyz, temp, idx, pts);
                     rc = mcp_launch_status();
                 }
             }
-        } else if (bs == 512) rc = launch_resident<512, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
-        else if (bs == 256) rc = launch_resident<256, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
-        else if (bs == 128) rc = launch_resident<128, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
-        else rc = launch_resident<64, 2, 0, false>(b, n, m, L, xyz, temp, idx, s);
+        } else if (bs == 512) rc = launch_resident<512, 2, 0, false>(b, n, m, L, xyz, temp, idx, pts, s);
+        else if (bs == 256) rc = launch_resident<256, 2, 0, false>(b, n, m, L, xyz, temp, idx, pts, s);
+        else if (bs == 128) rc = launch_resident<128, 2, 0, false>(b, n, m, L, xyz, temp, idx, pts, s);
+        else rc = launch_resident<64, 2, 0, false>(b, n, m, L, xyz, temp, idx, pts, s);
     } else {
-        rc = launch_resident<64, 1, 0, true>(b, n, m, L, xyz, temp, idx, s);  // n < 64
+        rc = launch_resident<64, 1, 0, true>(b, n, m, L, xyz, temp, idx, pts, s);  // n < 64
     }
     mcp_prof_end(MCP_KERNEL_FPS, s);
     return rc;
@@ -858,23 +879,24 @@ MCP_EXPORT size_t mcp_fps_workspace_bytes(int b, int n, int m) {
 MCP_EXPORT int mcp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && temp && idx);
     if (m <= 0) return MCP_OK;  // sampling_gpu.cu:100
-    return fps_dispatch(b, n, m, xyz, temp, idx, nullptr, 0, (hipStream_t)stream);
+    return fps_dispatch(b, n, m, xyz, temp, idx, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 MCP_EXPORT int mcp_furthest_point_sampling_ws(int b, int n, int m, const float *xyz, float *temp, int *idx, void *workspace,
                                               size_t workspace_bytes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && temp && idx);
     if (m <= 0) return MCP_OK;
-    return fps_dispatch(b, n, m, xyz, temp, idx, static_cast<char *>(workspace), workspace_bytes, (hipStream_t)stream);
+    return fps_dispatch(b, n, m, xyz, temp, idx, nullptr, static_cast<char *>(workspace), workspace_bytes, (hipStream_t)stream);
 }
 
 /* A fresh sampling (every call of the caller graph is one): the running distances start at 1e10 inside the kernel and are not
- * returned, so the caller neither fills nor allocates the (b,n) temp buffer of the reference interface.  Same indices as
- * mcp_furthest_point_sampling_ws with temp = 1e10.  MCP_ERR_UNSUPPORTED where only the streaming kernel applies (n > 65536, or
- * 16384 < n <= 65536 without workspace): use the temp interface there. */
-MCP_EXPORT int mcp_furthest_point_sampling_fresh(int b, int n, int m, const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                                                 mcp_stream_t stream) {
+ * returned, so the caller neither fills nor allocates the (b,n) temp buffer of the reference interface; sampled_xyz (b,m,3),
+ * optional, receives the coordinates of the selected points (the index_points_gather the callers run next, mocopci.py:1379).
+ * Same indices as mcp_furthest_point_sampling_ws with temp = 1e10.  MCP_ERR_UNSUPPORTED where only the streaming kernel applies
+ * (n > 65536, or 16384 < n <= 65536 without workspace): use the temp interface there. */
+MCP_EXPORT int mcp_furthest_point_sampling_fresh(int b, int n, int m, const float *xyz, int *idx, float *sampled_xyz, void *workspace,
+                                                 size_t workspace_bytes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && xyz && idx);
     if (m <= 0) return MCP_OK;
-    return fps_dispatch(b, n, m, xyz, nullptr, idx, static_cast<char *>(workspace), workspace_bytes, (hipStream_t)stream);
+    return fps_dispatch(b, n, m, xyz, nullptr, idx, sampled_xyz, static_cast<char *>(workspace), workspace_bytes, (hipStream_t)stream);
 }

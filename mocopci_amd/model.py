@@ -295,9 +295,7 @@ class MoCoPCI(nn.Module):
 
     def fps_gather(self, xyz, npoint, return_idx=False):
         """furthest_point_sample + index_points_gather (mocopci.py:1378-1379)."""
-        be = ops.backend()
-        sel = be.fps(xyz, npoint)
-        pts = be.group_rows(xyz, sel)
+        sel, pts = ops.backend().fps(xyz, npoint, with_points=True)   # one launch: the sample and its coordinates
         return (pts, sel) if return_idx else pts
 
     @staticmethod

@@ -87,23 +87,26 @@ class _GroupRowsFn(torch.autograd.Function):
 class HipBackend:
     name = "hip"
 
-    def fps(self, xyz, npoint):
-        """furthest_point_sample (pointnet2_utils.py:10-29): xyz (B,N,3) -> (B,npoint) int32."""
+    def fps(self, xyz, npoint, with_points=False):
+        """furthest_point_sample (pointnet2_utils.py:10-29): xyz (B,N,3) -> (B,npoint) int32.  with_points: also the sampled
+        coordinates (B,npoint,3) -- the index_points_gather that follows in every caller -- from the same launch."""
         xyz = xyz.detach()
         B, N, _ = xyz.shape
         out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
         need = _lib.load().mcp_fps_workspace_bytes(B, N, npoint)  # scratch for the tiled kernel (16384 < N <= 65536), else 0
         ws = torch.empty((need,), dtype=torch.uint8, device=xyz.device) if need else None
         if N <= 65536:  # a fresh sampling: the running distances stay inside the kernel (no (B,N) buffer to fill)
+            pts = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if with_points else None
             try:
-                _call("mcp_furthest_point_sampling_fresh", xyz, B, N, npoint, _lib.fptr(xyz), _lib.iptr(out), ws.data_ptr() if need else None, need)
-                return out
+                _call("mcp_furthest_point_sampling_fresh", xyz, B, N, npoint, _lib.fptr(xyz), _lib.iptr(out), None if pts is None else _lib.fptr(pts),
+                      ws.data_ptr() if need else None, need)
+                return (out, pts) if with_points else out
             except _lib.Unsupported:  # only the streaming kernel applies to this shape: it keeps its running distances in temp
                 pass
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
         _call("mcp_furthest_point_sampling_ws", xyz, B, N, npoint, _lib.fptr(xyz), _lib.fptr(temp), _lib.iptr(out),
               ws.data_ptr() if need else None, need)
-        return out
+        return (out, self.group_rows(xyz, out)) if with_points else out
 
     # clouds at least this large go through the Morton-sorted, box-pruned search (same results)
     # (plain attributes: A/B tools set them on the class; the package reads no tuning variables from the environment)

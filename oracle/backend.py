@@ -34,8 +34,9 @@ class OracleBackend:
         x = fea[src_self.long()] + te_self[:, None, :]
         return x, torch.addcmul(shift, x, scale), torch.addcmul(shift, fea[src_partner.long()] + te_partner[:, None, :], scale)
 
-    def fps(self, xyz, npoint):
-        return orc.furthest_point_sample(xyz.detach(), npoint)
+    def fps(self, xyz, npoint, with_points=False):
+        sel = orc.furthest_point_sample(xyz.detach(), npoint)
+        return (sel, self.group_rows(xyz, sel)) if with_points else sel
 
     def knn(self, query, ref, k, mode=0, return_dist=False):
         return orc.knn(query.detach(), ref.detach(), k, mode=mode, return_dist=return_dist)

@@ -695,3 +695,15 @@ def test_mfa_prepare_matches_torch():
     assert torch.equal(got[0].cpu(), want[0])
     for a, b in zip(got[1:], want[1:]):
         torch.testing.assert_close(a.cpu(), b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("b,n,m", [(3, 8192, 2048), (2, 2048, 512), (2, 512, 256), (2, 256, 64), (1, 50, 7), (2, 20000, 300), (1, 70000, 64)])
+def test_fps_fresh_start_with_points_matches_the_two_step_form(b, n, m):
+    """mcp_furthest_point_sampling_fresh: no temp buffer, optional sampled coordinates from the same launch -- the same indices as
+    the reference-signature entry point with temp = 1e10 (bit-exact, every kernel variant: resident, spatial, tiled, and the
+    streaming fallback beyond 65536 points) and exactly the rows a gather of them returns."""
+    xyz = cloud(7 + n, b, n).to(DEV)
+    sel, pts = ops.backend().fps(xyz, m, with_points=True)
+    assert torch.equal(sel, pu.furthest_point_sample(xyz, m))
+    assert torch.equal(pts, ops.backend().group_rows(xyz, sel))
+    assert torch.equal(sel.cpu(), orc.furthest_point_sample(xyz.cpu(), m))
