@@ -21,6 +21,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int MAXSEG = 3;
+constexpr long long MCP_LINEAR_SPLITK_ROWS = 16384;  // below this the split-K kernel (see linear_splitk_kernel)
 
 struct Segs {
     const float *x[MAXSEG];
@@ -235,6 +236,159 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_kernel(long long rows, int 
     }
 }
 
+// ---- few rows, long K: split-K (r3) -----------------------------------------------------------------------------------------
+// The layers of the lower pyramid levels have 1024 .. 8192 rows and K up to 2072 (PointConv projections (3+D)*8 -> C, the q / kv
+// projections of cross_block3, ...): linear_kernel gives a wave 32 rows and the whole K loop, i.e. 32 .. 256 waves on 1024 SIMDs,
+// and the library's f32 GEMMs take 15 .. 65 us for a few GFLOP there (one 63 us call at level 3).  Here the FOUR waves of a
+// workgroup share one 32-row tile and split its K chunks between them (wave w takes chunks w, w+4, ...), a workgroup covers
+// NT <= 2 output tiles (grid.y runs over the rest), so 4096 rows x 256 columns are 512 workgroups; the weight pieces come
+// straight from the packed image in L2 into registers (every wave reads different chunks: nothing to share through LDS, no
+// barrier in the K loop), one chunk ahead, like the x tile; the four partial accumulators are summed in a fixed order through
+// LDS by wave 0, which then runs the same epilogue as linear_kernel.  Same split-bf16 arithmetic, deterministic.
+template <int NT>
+__global__ __launch_bounds__(256) void linear_splitk_kernel(long long rows, int n, Segs sg, int nseg, int total_chunks, float slope,
+                                                            const float *__restrict__ packed, int cf_total, const float *__restrict__ res, int rs_,
+                                                            float *__restrict__ out, int os_) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // x tiles [4][XT] | partial accumulators [3][NT][16][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    const int cr = lane >> 3, cq = lane & 7;
+    float *tile = lds + wave * XT;
+    float *part = lds + 4 * XT;
+    const int tb = blockIdx.y * NT;
+    const long long row0 = (long long)blockIdx.x * 32;
+    f32x16 acc[NT];
+    {
+        const float *bi = packed + (size_t)total_chunks * cf_total + tb * 32;  // wave 0 starts from the bias, the others from zero
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = wave == 0 ? bi[(t * 2 + h) * 16 + r] : 0.f;
+    }
+    long long xrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xrow[j] = min(row0 + 8 * j + cr, rows - 1);
+    const int c1 = sg.chunks[0], c2 = c1 + (nseg > 1 ? sg.chunks[1] : 0);
+    struct Tile { float4 v[4]; };
+    struct Wts { u32x4 w[NT][2][3]; };
+    // chunk ci of the concatenated K axis: x tile (masked past a piece's width) and the weight pieces of this workgroup's tiles;
+    // `live` false: a dummy re-read of chunk 0 whose x tile is zero (keeps the loop body branch-free: exact wait counts)
+    auto request = [&](int ci_, bool live, Tile &g, Wts &wt) {
+        const int ci = live ? ci_ : 0;
+        const int sgi = (ci >= c1) + (ci >= c2);
+        const int cci = ci - (sgi == 0 ? 0 : sgi == 1 ? c1 : c2);
+        const float *xb = sgi == 0 ? sg.x[0] : sgi == 1 ? sg.x[1] : sg.x[2];
+        const int stride = sgi == 0 ? sg.stride[0] : sgi == 1 ? sg.stride[1] : sg.stride[2];
+        const int kk = sgi == 0 ? sg.k[0] : sgi == 1 ? sg.k[1] : sg.k[2];
+        const bool ok = live && 32 * cci + 4 * cq < kk;
+        const uint32_t mask = ok ? 0xFFFFFFFFu : 0u;
+        const float *base = xb + (ok ? 32 * cci + 4 * cq : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(base + xrow[j] * stride);
+            g.v[j] = make_float4(__uint_as_float(v.x & mask), __uint_as_float(v.y & mask), __uint_as_float(v.z & mask), __uint_as_float(v.w & mask));
+        }
+        const u32x4 *wc = reinterpret_cast<const u32x4 *>(packed + (size_t)ci * cf_total) + (size_t)tb * 2 * 3 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) wt.w[t][s2][pc] = wc[(size_t)((t * 2 + s2) * 3 + pc) * 64];
+    };
+    const int mine = total_chunks > wave ? (total_chunks - wave + 3) / 4 : 0;  // chunks wave, wave + 4, ...
+    Tile xa_, xb_;
+    Wts wa_, wb_;
+    request(wave, mine > 0, xa_, wa_);
+    for (int i = 0; i < mine; ++i) {
+        request(wave + 4 * (i + 1), i + 1 < mine, xb_, wb_);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(tile + (8 * j + cr) * XP + 4 * cq) = xa_.v[j];
+        f32x16 xa;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(tile + col * XP + 8 * g + 4 * h);
+            xa[4 * g + 0] = v.x; xa[4 * g + 1] = v.y; xa[4 * g + 2] = v.z; xa[4 * g + 3] = v.w;
+        }
+        McpSplit3 xs[2];
+        xs[0] = mcp_split_kstep(xa, 0);
+        xs[1] = mcp_split_kstep(xa, 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint4 w1 = __builtin_bit_cast(uint4, wa_.w[t][s2][0]), w2 = __builtin_bit_cast(uint4, wa_.w[t][s2][1]),
+                            w3 = __builtin_bit_cast(uint4, wa_.w[t][s2][2]);
+                acc[t] = mcp_mfma_bf16(w3, xs[s2].p1, acc[t]);  // small terms first, as mcp_mfma_split
+                acc[t] = mcp_mfma_bf16(w1, xs[s2].p3, acc[t]);
+                acc[t] = mcp_mfma_bf16(w2, xs[s2].p2, acc[t]);
+                acc[t] = mcp_mfma_bf16(w2, xs[s2].p1, acc[t]);
+                acc[t] = mcp_mfma_bf16(w1, xs[s2].p2, acc[t]);
+                acc[t] = mcp_mfma_bf16(w1, xs[s2].p1, acc[t]);
+            }
+        xa_ = xb_;
+        wa_ = wb_;
+    }
+    // fixed-order sum of the four partial accumulators: waves 1..3 publish, wave 0 adds 1, 2, 3
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[(((wave - 1) * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += part[((w * NT + t) * 16 + r) * 64 + lane];
+    const bool vec = !(os_ & 3) && !(((uintptr_t)out) & 15) && !(res && ((rs_ & 3) || (((uintptr_t)res) & 15)));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a = acc[t][4 * g + u];
+                v[u] = a > 0.f ? a : a * slope;
+            }
+            *reinterpret_cast<float4 *>(tile + col * XP + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        const int ch = 32 * (tb + t) + 4 * cq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long row = row0 + 8 * j + cr;
+            const float4 v4 = *reinterpret_cast<const float4 *>(tile + (8 * j + cr) * XP + 4 * cq);
+            if (row >= rows || ch >= n) continue;
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            float *orow = out + row * os_;
+            const float *rrow = res ? res + row * rs_ : nullptr;
+            if (vec && ch + 3 < n) {
+                if (rrow) {
+                    const float4 r4 = *reinterpret_cast<const float4 *>(rrow + ch);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                *reinterpret_cast<float4 *>(orow + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ch + u < n) orow[ch + u] = v[u] + (rrow ? rrow[ch + u] : 0.f);
+            }
+        }
+    }
+}
+
+template <int NT>
+int launch_linear_splitk(long long rows, int n, int nt_total, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res,
+                         int rs_, float *out, int os_, hipStream_t s) {
+    const size_t lds = (4 * (size_t)XT + 3 * (size_t)NT * 16 * 64) * sizeof(float);
+    hipLaunchKernelGGL(linear_splitk_kernel<NT>, dim3((unsigned)((rows + 31) / 32), nt_total / NT), dim3(256), lds, s, rows, n, sg, nseg, total_chunks, slope,
+                       packed, chunk_floats(nt_total), res, rs_, out, os_);
+    return mcp_launch_status();
+}
+
 template <int NT, int KC, int NW>
 int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
                      float *out, int os_, hipStream_t s, int col_blocks = 1) {
@@ -392,6 +546,12 @@ MCP_EXPORT int mcp_linear(long long rows, int n, int nseg, const float *const *x
     const int nt = (n + 31) / 32, total = count_chunks(nseg, k_seg);
     int rc;
     mcp_prof_begin(MCP_KERNEL_LINEAR, s);
+    if (rows < MCP_LINEAR_SPLITK_ROWS && total >= 4) {  // few rows: four waves split the K chunks of one 32-row tile
+        rc = (nt & 1) ? launch_linear_splitk<1>(rows, n, nt, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s)
+                      : launch_linear_splitk<2>(rows, n, nt, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s);
+        mcp_prof_end(MCP_KERNEL_LINEAR, s);
+        return rc;
+    }
     switch (nt) {
         case 1: rc = launch_linear<1>(rows, n, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s); break;
         case 2: rc = launch_linear<2>(rows, n, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s); break;

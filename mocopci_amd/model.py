@@ -205,7 +205,7 @@ class MoCoPCI(nn.Module):
         w, b = self.W(name), self.Bv(name)
         be = ops.backend()
         pieces = isinstance(x, (tuple, list))  # the pieces of a concatenation along the channel axis: read in place by the kernel
-        if be.linear_supported(list(x) if pieces else x, w.shape[0]):
+        if be.linear_supported(list(x) if pieces else x, w.shape[0], few_rows=self._live is None):
             ks = [t.shape[-1] for t in x] if pieces else [x.shape[-1]]
             packed = None if self._live is not None else self.derived(("lin_pack", be.name, name, tuple(ks)), lambda: be.linear_pack(w, b, ks))
             return be.linear(list(x) if pieces else x, w, b, slope, res, packed=packed)
@@ -295,7 +295,12 @@ class MoCoPCI(nn.Module):
 
     def fps_gather(self, xyz, npoint, return_idx=False):
         """furthest_point_sample + index_points_gather (mocopci.py:1378-1379)."""
-        sel, pts = ops.backend().fps(xyz, npoint, with_points=True)   # one launch: the sample and its coordinates
+        be = ops.backend()
+        if xyz.requires_grad and torch.is_grad_enabled():  # training: the gather carries the gradient to the (warped) coordinates
+            sel = be.fps(xyz, npoint)
+            pts = be.group_rows(xyz, sel)
+        else:
+            sel, pts = be.fps(xyz, npoint, with_points=True)          # one launch: the sample and its coordinates
         return (pts, sel) if return_idx else pts
 
     @staticmethod
@@ -773,7 +778,7 @@ class MoCoPCI(nn.Module):
     def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None, idx_c12=None):
         """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C)."""
         c1, c2 = (f1_0, f1_1, f1_new), (f2_0, f2_1, f2_new)
-        if not ops.backend().linear_supported(list(c1), self.W(prefix + ".bid.cross_t11").shape[0]):
+        if not ops.backend().linear_supported(list(c1), self.W(prefix + ".bid.cross_t11").shape[0], few_rows=self._live is None):
             c1, c2 = torch.cat(c1, dim=-1), torch.cat(c2, dim=-1)  # library path: concatenate once, both projections read it
         b, fe = prefix + ".bid", prefix + ".fe"
         t11_1, t22_2 = self.lin(c1, b + ".cross_t11"), self.lin(c2, b + ".cross_t22")
@@ -880,7 +885,7 @@ class MoCoPCI(nn.Module):
             return (w3 @ self.W(prefix + ".fc1")).contiguous(), (w3 @ self.Bv(prefix + ".fc1")).contiguous()
         w, b = self.derived(("qkv_fold", prefix), fold)
         be = ops.backend()
-        if be.linear_supported(feats, w.shape[0]):  # tall inputs: the fused per-point Linear (67 vs 86 us at 196608 rows)
+        if be.linear_supported(feats, w.shape[0], few_rows=self._live is None):  # tall inputs: the fused per-point Linear (67 vs 86 us at 196608 rows)
             packed = None if self._live is not None else self.derived(("qkv_pack", be.name, prefix), lambda: be.linear_pack(w, b, [feats.shape[-1]]))
             return be.linear(feats, w, b, 1.0, None, packed=packed)
         return F.linear(feats, w, b)

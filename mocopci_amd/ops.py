@@ -452,19 +452,27 @@ class HipBackend:
             out.append(v)
         return out
 
-    def linear_supported(self, xs, n):
+    def linear_supported(self, xs, n, few_rows=True):
         """Whether linear() takes this call.  Beyond what the kernel can do, a shape policy: the fused kernel beats the BLAS
         chain for tall inputs with moderate K (tools/linear_ab.py, MI355X: 1.3-1.9x at rows >= 16384, K <= 320, e.g. 58 -> 31 us
         for 196608 x 32 -> 64 + LeakyReLU) and, since its K loop is staged four chunks per barrier, for the K = 536 -> 64 PointConv
         projections (171 -> 146 us at 196608 rows); it loses for few rows (one 256-row workgroup per 8 waves: 2048-8192 rows do
-        not cover the chip) and for long K at wide N (2072 -> 256), which stay on the library."""
+        not cover the chip) and for long K at wide N (2072 -> 256), which stay on the library.  few_rows=False: without the
+        split-K few-row kernel (a training forward keeps the library's fp32 GEMMs there, as the gradient tests were pinned)."""
         if self._NO_LINEAR:
             return False
         ps = self._pieces(xs)
         if ps is None or len(ps) > 3 or len({p.shape[0] for p in ps}) != 1:
             return False
         k = sum(p.shape[1] for p in ps)
-        if ps[0].shape[0] < self._LIN_MIN_ROWS or n > self._LIN_MAX_N or (k > self._LIN_MAX_K and not (k <= 2 * self._LIN_MAX_K and n <= 64)):
+        rows = ps[0].shape[0]
+        if few_rows and self._LIN_FEW_MIN_ROWS <= rows < self._LIN_MIN_ROWS:
+            # few rows (the lower pyramid levels): the split-K kernel -- four waves share a 32-row tile and split its K chunks -- beats
+            # the library GEMM + activation pair up to 256 output columns (tools/linear_fewrows_ab.py: 33 -> 26 us at 4096 x 1048 ->
+            # 256, 25 -> 12 us at 8192 x 128 -> 128); wider outputs re-read and re-split x per 64-column block and lose
+            if n > 256 or k < 64 or k > self._LIN_FEW_MAX_K:
+                return False
+        elif rows < self._LIN_MIN_ROWS or n > self._LIN_MAX_N or (k > self._LIN_MAX_K and not (k <= 2 * self._LIN_MAX_K and n <= 64)):
             return False
         ks = (ctypes.c_int * len(ps))(*[p.shape[1] for p in ps])
         return _lib.load().mcp_linear_packed_floats(n, len(ps), ks) != 0
@@ -473,6 +481,8 @@ class HipBackend:
     _NO_LINEAR = False
     _NO_NARROW = False
     _LIN_MIN_ROWS = 16384
+    _LIN_FEW_MIN_ROWS = 2048   # rows from which the split-K few-row kernel is used (0 < rows < _LIN_MIN_ROWS); 1 << 30 turns it off
+    _LIN_FEW_MAX_K = 1100
     _LIN_MAX_K = 320
     _LIN_MAX_N = 192
 

@@ -586,7 +586,7 @@ def test_linear_matches_unfused_oracle(rows, ks, n, slope, with_res):
     got = be.linear(xd if len(xd) > 1 else xd[0], w.to(DEV), b.to(DEV), slope, None if res is None else res.to(DEV))
     torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
     # shapes outside the policy are declined (the caller then takes the BLAS chain)
-    assert not be.linear_supported(xd[0][:2048], n) and not be.linear_supported(torch.empty(20000, 700, device=DEV), 64)
+    assert not be.linear_supported(xd[0][:1000], n) and not be.linear_supported(torch.empty(20000, 700, device=DEV), 64)
     assert not be.linear_supported(torch.empty(20000, 600, device=DEV), 128)
 
 
@@ -707,3 +707,26 @@ def test_fps_fresh_start_with_points_matches_the_two_step_form(b, n, m):
     assert torch.equal(sel, pu.furthest_point_sample(xyz, m))
     assert torch.equal(pts, ops.backend().group_rows(xyz, sel))
     assert torch.equal(sel.cpu(), orc.furthest_point_sample(xyz.cpu(), m))
+
+
+@pytest.mark.parametrize("rows,ks,n,slope,with_res", [(4096, [1048], 256, 0.1, False), (8192, [536], 128, 0.1, False), (2048, [512], 256, 1.0, True),
+                                                      (4100, [64, 64, 64], 96, 0.1, True), (3000, [256], 32, 0.0, False), (5000, [128, 32], 192, 0.25, True)])
+def test_linear_few_rows_split_k_matches_unfused_oracle(rows, ks, n, slope, with_res):
+    """Below 16384 rows mcp_linear runs the split-K kernel (four waves share a 32-row tile and split its K chunks; fixed-order sum of
+    the partial accumulators): pieces, a row-strided piece, residual, odd tile counts (NT = 1 path) and ragged row counts, against
+    the oracle backend's cat - Linear - activation - residual; bit-reproducible from call to call."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(rows + n)
+    wide = torch.randn(rows, ks[0] + 12, generator=g)
+    xs = [wide[:, 4:4 + ks[0]]] + [torch.randn(rows, k, generator=g) for k in ks[1:]]
+    w, b = torch.randn(n, sum(ks), generator=g) / sum(ks) ** 0.5, torch.randn(n, generator=g) * 0.1
+    res = torch.randn(rows, n, generator=g) if with_res else None
+    want = OracleBackend().linear(xs, w, b, slope, res)
+    be = ops.backend()
+    wd = wide.to(DEV)
+    xd = [wd[:, 4:4 + ks[0]]] + [t.to(DEV) for t in xs[1:]]
+    assert be.linear_supported(xd, n)
+    call = lambda: be.linear(xd if len(xd) > 1 else xd[0], w.to(DEV), b.to(DEV), slope, None if res is None else res.to(DEV))
+    got = call()
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
+    assert torch.equal(call(), got)
