@@ -26,6 +26,22 @@
 #include "common.h"
 #include "mfma_split.h"
 
+#ifdef MCP_CROSS_DIAG
+// diagnostic build only (never in the product library): shader-cycle totals per phase of the per-point loop, wave 0 of workgroup 0
+__device__ unsigned long long g_cross_diag[8];
+#define CROSS_STAMP(slot)                                                                            \
+    do {                                                                                             \
+        unsigned long long t_;                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_cross_diag[slot] += t_ - t_prev; \
+        t_prev = t_;                                                                                 \
+    } while (0)
+#else
+#define CROSS_STAMP(slot)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -218,7 +234,12 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
         fetch(p, qp, nbr(p, qp));
         if (pn < total) idn = nbr(pn, qn);
     }
+#ifdef MCP_CROSS_DIAG
+    unsigned long long t_prev = 0;
+    CROSS_STAMP(7);
+#endif
     for (; p < total; p = pn, pn += stride) {
+        CROSS_STAMP(0);  // loop overhead / previous store
         f32x16 x0[L::BF ? 1 : T];
         McpSplit3 xs[L::BF ? 2 * T : 1];
         const float in0 = h ? q2y - p1y : q2x - p1x, in1 = h ? 1.0f : q2z - p1z;  // k-step 0: (dx,dy); k-step 1: (dz,1)
@@ -249,12 +270,14 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
             }
         }
         __builtin_amdgcn_wave_barrier();  // the row has been read: the next point's may be written over it
+        CROSS_STAMP(1);  // x0 build: waits for the prefetched loads, pos MFMA, epilogue, split
         if (pn < total) {
             fetch(pn, qn, idn);
             if (pn + stride < total) idn = nbr(pn + stride, qnn);
         }
         qn = qnn;
         qnn = advance(qnn);
+        CROSS_STAMP(2);  // issue of the next point's loads
 #pragma unroll 1
         for (int tl = 0; tl < TO; ++tl) {
             const int t = TO * split + tl;
@@ -275,8 +298,10 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x0[tin][r0 + 3], acc, 0, 0, 0);
                 }
             }
+            CROSS_STAMP(3);  // D x D tile: bias + MFMA chain
             const float m = leaky(scatter_max(acc, lane));  // leaky is monotone: it commutes with the max
             if ((lane & 1) == 0) out[p * D + 32 * t + chan_of(scatter_reg(lane), h)] = m;
+            CROSS_STAMP(4);  // neighbour max + store
         }
     }
 }
@@ -337,3 +362,12 @@ MCP_EXPORT int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float
     mcp_prof_end(MCP_KERNEL_CROSS, s);
     return rc;
 }
+
+#ifdef MCP_CROSS_DIAG
+MCP_EXPORT int mcp_cross_diag_read(unsigned long long *out8) {
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cross_diag), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cross_diag), z, sizeof(z));
+    return (int)e;
+}
+#endif
