@@ -139,3 +139,19 @@ def test_quality_metric_reacts_to_a_wrong_neighbour_search(oracle_backend):
     e_gt2 = float((gt[0] ** 2).sum(-1).mean())
     assert max(good) < 0.05 * e_gt2, (good, e_gt2)
     assert min(abs(b - a) / a for a, b in zip(good, bad)) > 0.10, (good, bad)
+
+
+def test_serving_loop_api_without_streams(oracle_backend):
+    """prefetch / begin / finish on a backend without streams (CPU): prefetch has nothing to issue ahead (None handle), begin runs the
+    whole forward, finish hands its result over -- the loop bench.py runs is valid everywhere and returns what forward() returns."""
+    import torch
+    from mocopci_amd import synth
+    net = hc.build_model("cpu")
+    x1, x2, _ = synth.make_batch(1, 1, 256)
+    want = net(x1, x2)
+    assert net.prefetch(x1, x2) is None
+    pending = net.begin(x1, x2, prefetched=None, then_prefetch=(x1, x2))
+    assert net.take_prefetched() is None
+    got = net.finish(pending)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert all(torch.equal(a, b) for a, b in zip(net(x1, x2, prefetched=None, then_prefetch=(x1, x2)), want))
