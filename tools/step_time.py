@@ -16,7 +16,7 @@ for a in sys.argv[1:]:
     elif "=" in a and not a.startswith("--"):
         k, v = a.split("=")
         setattr(ops.HipBackend, k, type(getattr(ops.HipBackend, k))(int(v)) if not isinstance(getattr(ops.HipBackend, k), bool) else v == "1")
-net = MoCoPCI(); net.load_state_dict(synth.weights_by_name(net._spec)); net = net.cuda()
+net = MoCoPCI(); net.load_state_dict((synth.weights_on_scan if "--scan-weights" in sys.argv else synth.weights_by_name)(net._spec)); net = net.cuda()
 x1, x2, _ = synth.make_batch(2, 8, 8192, device="cuda")
 ev = torch.cuda.Event(); ev.record()
 
