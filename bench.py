@@ -52,7 +52,7 @@ NAMES = {
     "knn_cosine": "knn_cosine_kernel (mcp_knn_cosine)",
     "fusion": "fusion_split_kernel (mcp_fusion)",
     "cross": "cross_kernel<64|128|256> (mcp_cross_volume)",
-    "pointconv": "pointconv_agg_kernel (mcp_pointconv_agg)",
+    "pointconv": "pointconv_linear_kernel / pointconv_agg_kernel (mcp_pointconv_linear, mcp_pointconv_agg)",
     "attention": "attention_small_kernel<8|16> / attention_wide_kernel<32|256> (mcp_attention_small, mcp_attention_wide)",
     "ptblock": "ptblock_kernel (mcp_ptblock_attention)",
     "mlp": "mlp2_kernel (mcp_mlp2)",
@@ -70,7 +70,8 @@ NOTES = {
               "split: peak = bf16 dense MFMA peak / 6 partial products per fp32 product",
     "cross": "B*N1*K*(8C+2C^2) flop; D=64/128 on the split-bf16 path (peak as for fusion), the one D=256 launch per step on the f32-input MFMA",
     "pointconv": "gather + WeightNet + aggregation on the VALU; achieved = gathered rows + aggregate written, B*S*(K*4*(D+3) + 32*(D+3)) bytes "
-                 "(the gathers hit L2 / Infinity Cache)",
+                 "(the gathers hit L2 / Infinity Cache).  The D = 32 / 64 launches (levels 0, 1, refinement) also run the Linear + LeakyReLU behind "
+                 "the aggregation (mcp_pointconv_linear): their aggregate stays in LDS, so they move LESS than this figure and do more",
     "attention": "4*BF*H*Nq*Nk*hd flop; S = QK^T on the f32-input MFMA, softmax and (head dims 8/16) P.V on the VALU",
     "ptblock": "B*N*16*2*(3*64 + 3*64^2) flop; the three 64x64 layers on the split-bf16 path",
     "mlp": "2*rows*(C*H + H*C_out) flop of the fused Mlp_T / flow-head blocks on the split-bf16 path, weights streamed through LDS",
@@ -131,7 +132,7 @@ def log_call_shapes(be, step):
     3-NN searches inside interp3 / interp3_search reach the timer through be.knn, so only be.knn records them; the fused
     small-level mcp_interp3 call (its own KNN launch inside the library) records here."""
     calls = {k: [] for k in FAMILIES}
-    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "attention", "attention_rot", "ptblock_attention", "mlp2", "linear",
+    names = ("fps", "knn", "interp3", "knn_cosine", "fusion_mlp", "cross_volume", "pointconv_agg", "pointconv_linear", "attention", "attention_rot", "ptblock_attention", "mlp2", "linear",
              "linear_narrow")
     orig = {n: getattr(be, n) for n in names}
 
@@ -152,6 +153,7 @@ def log_call_shapes(be, step):
     be.fusion_mlp = wrap("fusion_mlp", lambda p1, *a: calls["fusion"].append((p1.shape[0], p1.shape[1])))
     be.cross_volume = wrap("cross_volume", lambda x1, x2, f1, *a, **k: calls["cross"].append((x1.shape[0], x1.shape[1], f1.shape[2])))
     be.pointconv_agg = wrap("pointconv_agg", lambda sx, nx, sp, *a: calls["pointconv"].append((nx.shape[0], nx.shape[1], sp.shape[2])))
+    be.pointconv_linear = wrap("pointconv_linear", lambda sx, nx, sp, *a, **k: calls["pointconv"].append((nx.shape[0], nx.shape[1], sp.shape[2])))
     be.attention = wrap("attention", lambda q, kv, h, **kw: calls["attention"].append((q.shape[0], h, q.shape[1], kv.shape[1], q.shape[2] // h)))
     be.attention_rot = wrap("attention_rot", lambda q, k, v, h, *a, **kw: calls["attention"].append((q.shape[0], h, q.shape[1], k.shape[1], q.shape[2] // h)))
     be.ptblock_attention = wrap("ptblock_attention", lambda xyz, q, *a: calls["ptblock"].append((q.shape[0], q.shape[1])))

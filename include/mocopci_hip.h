@@ -220,6 +220,17 @@ int mcp_pointconv_agg(int b, int n, int s, int d, int k, const float *s_xyz, con
                       const int *idx, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                       const float *b2, float *out, mcp_stream_t stream);
 
+/* PointConv / PointConvD after the sampling as ONE launch (models/m_models/mocopci.py:1330-1342 and :1381-1393: group + WeightNet +
+ * matmul + Linear((3+D)*8 -> C_out) + LeakyReLU): the (B,S,(3+D)*8) aggregate stays on the compute unit.  Arguments as
+ * mcp_pointconv_agg, then `packed`: the mcp_linear_pack image of the Linear's (C_out, (3+D)*8) weight (one piece) with its bias;
+ * `slope`: the activation's negative slope (0.1 in the reference; 1 = none); out (B,S,C_out).
+ * (D, C_out) = (32, 32) or (64, 64), k = 32; anything else returns MCP_ERR_UNSUPPORTED (use mcp_pointconv_agg + mcp_linear).
+ * From 16384 rows (B*S) up the result is bit-identical to mcp_pointconv_agg followed by mcp_linear (same operand split, same
+ * summation order); below that mcp_linear sums K in four parts and the two differ in the last bits. */
+int mcp_pointconv_linear(int b, int n, int s, int d, int k, const float *s_xyz, const float *new_xyz, const float *s_points,
+                         const int *idx, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
+                         const float *b2, const float *packed, int c_out, float slope, float *out, mcp_stream_t stream);
+
 /* Multi-head attention with a tiny head dim (8 or 16) in exact fp32, flash style (no (N,N) score tensor):
  * the attention core of InterFrameAttentionInterpretation (mocopci.py:650-667) and CrossAttention (:72-86).
  * q (BF,Nq,*), k/v (BF,Nk,*) are read in place from the projection outputs: element [bf, token, head*hd + d]

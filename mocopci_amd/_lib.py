@@ -50,6 +50,7 @@ SIGNATURES = {
     "mcp_cross_pack": [_i, _p, _p, _p, _p, _p, _p],
     "mcp_cross_volume": [_i] * 5 + [_p] * 7 + [_i, _p, _p, _p],
     "mcp_pointconv_agg": [_i] * 5 + [_p] * 12,
+    "mcp_pointconv_linear": [_i] * 5 + [_p] * 11 + [_i, _f, _p, _p],
     "mcp_attention_small": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
     "mcp_attention_wide": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
     "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],

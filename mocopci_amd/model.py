@@ -98,6 +98,7 @@ class MoCoPCI(nn.Module):
     drop_path_rate = 0.04   # stochastic depth of Multi_Frame_Att's two residual branches (Cross_Frame_Att: 0)
     BN_MOMENTUM = 0.1       # nn.BatchNorm default
     PAIR_CFA = True         # inference: cross_block3 evaluated once for both decoder directions (it is symmetric in its two frames)
+    FUSE_POINTCONV = True  # PointConv's Linear inside the grouped kernel where it is built for the shape (A/B switch)
     FOLD_EI = True          # inference: EI cross-formers in their folded 9-launch form (A/B: tools/step_time.py net.FOLD_EI=0)
 
     def __init__(self):
@@ -290,6 +291,11 @@ class MoCoPCI(nn.Module):
         if idx is None:
             idx = be.knn(new_xyz, s_xyz, nsample)
         wn = [t for i in range(3) for t in (self.W(f"{prefix}.weightnet.mlp_convs.{i}"), self.Bv(f"{prefix}.weightnet.mlp_convs.{i}"))]
+        w, b = self.W(prefix + ".linear"), self.Bv(prefix + ".linear")
+        if self.FUSE_POINTCONV and self._live is None and be.pointconv_linear_supported(s_points.shape[-1], w.shape[0], idx.shape[-1], rows=B * S):
+            # levels 0 / 1 and the refinement stage: the (B,S,(3+D)*8) aggregate never leaves the compute unit
+            packed = self.derived(("lin_pack", be.name, prefix + ".linear", (w.shape[1],)), lambda: be.pointconv_linear_pack(w, b))
+            return be.pointconv_linear(s_xyz, new_xyz, s_points.contiguous(), idx, *wn, w, b, LEAKY, packed=packed)
         agg = be.pointconv_agg(s_xyz, new_xyz, s_points.contiguous(), idx, *wn)      # (B,S,(3+D)*8)
         return self.lin(agg, prefix + ".linear", slope=LEAKY)
 

@@ -374,6 +374,32 @@ class HipBackend:
               _lib.iptr(idx), _lib.fptr(w0), _lib.fptr(b0), _lib.fptr(w1), _lib.fptr(b1), _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(out))
         return out
 
+    _PCL_MIN_ROWS = 16384   # from here mcp_linear runs linear_kernel, whose arithmetic the one-launch form reproduces bit for bit
+
+    def pointconv_linear_supported(self, d, c_out, k=32, rows=None):
+        """Shapes mcp_pointconv_linear is built for (levels 0 / 1 of the encoder and the refinement stage's PointConvD).  With
+        `rows` (= B * S centres): whether the model should use it -- only where its output is bit-identical to pointconv_agg +
+        linear, i.e. where that Linear would run the full-K kernel and not the split-K / library forms of the few-row launches."""
+        return k == 32 and (d, c_out) in ((32, 32), (64, 64)) and (rows is None or rows >= self._PCL_MIN_ROWS)
+
+    def pointconv_linear_pack(self, w, b):
+        """Operand image of PointConv's Linear: the same image linear() uses for the (B,S,(3+D)*8) aggregate."""
+        return self.linear_pack(w, b, [w.shape[1]])
+
+    def pointconv_linear(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2, w, b, slope, packed=None):
+        """PointConv after the sampling in one launch (mocopci.py:1330-1342): grouping, WeightNet, aggregation, Linear, LeakyReLU ->
+        (B,S,C_out).  Inference only (a training forward uses pointconv_agg + linear, which carry gradients).
+        packed: pointconv_linear_pack(w, b) if kept."""
+        s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2 = (t.contiguous() for t in (s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2))
+        B, N, D = s_points.shape
+        S, n = new_xyz.shape[1], w.shape[0]
+        pk = packed if packed is not None else self.pointconv_linear_pack(w, b)
+        out = torch.empty((B, S, n), dtype=torch.float32, device=s_points.device)
+        _call("mcp_pointconv_linear", s_points, B, N, S, D, idx.shape[-1], _lib.fptr(s_xyz), _lib.fptr(new_xyz), _lib.fptr(s_points),
+              _lib.iptr(idx), _lib.fptr(w0), _lib.fptr(b0), _lib.fptr(w1), _lib.fptr(b1), _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(pk), n,
+              float(slope), _lib.fptr(out))
+        return out
+
     def attention(self, q, kv, heads, scale=None):
         """softmax(q k^T * scale) v per head, reading the projection outputs in place: q (BF,Nq,C), kv (BF,Nk,2C)
         laid out [k | v] as the reference's kv Linear produces (mocopci.py:74-75, :653-654) -> (BF,Nq,C)."""

@@ -142,6 +142,16 @@ class OracleBackend:
             w = torch.relu(F.linear(w, ww, bb))
         return torch.matmul(new_points.transpose(2, 3), w).reshape(B, S, -1)
 
+    def pointconv_linear_supported(self, d, c_out, k=32, rows=None):
+        return True
+
+    def pointconv_linear_pack(self, w, b):
+        return None
+
+    def pointconv_linear(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2, w, b, slope, packed=None):
+        """mocopci.py:1330-1342: the aggregate above, then Linear and LeakyReLU."""
+        return self.linear(self.pointconv_agg(s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2), w, b, slope)
+
     def attention(self, q, kv, heads, scale=None):
         BF, Nq, C = q.shape
         Nk = kv.shape[1]

@@ -301,6 +301,37 @@ def test_pointconv_agg_matches_unfused_oracle(n, s, d):
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("n,s,d,B", [(8192, 8192, 32, 2), (8192, 2048, 64, 8), (3000, 2731, 64, 6), (700, 333, 32, 1), (515, 77, 64, 2)])
+def test_pointconv_linear_matches_the_two_kernel_form_and_the_oracle(n, s, d, B):
+    """mcp_pointconv_linear (grouping + WeightNet + aggregation + Linear + LeakyReLU in one launch, mocopci.py:1330-1342) against
+    the unfused oracle restatement and against mcp_pointconv_agg + mcp_linear: BIT-IDENTICAL from 16384 centres up (where the
+    model uses it); ragged point counts (partial last workgroup)."""
+    from oracle.backend import OracleBackend
+    g = torch.Generator().manual_seed(n + d)
+    xyz = cloud(93, B, n)
+    new_xyz = xyz[:, :s].contiguous()
+    pts = torch.randn(B, n, d, generator=g)
+    idx = orc.knn(new_xyz, xyz, 32)
+    wn = [torch.randn(8, 3, generator=g) * 0.3, torch.randn(8, generator=g) * 0.1, torch.randn(8, 8, generator=g) * 0.3,
+          torch.randn(8, generator=g) * 0.1, torch.randn(8, 8, generator=g) * 0.3, torch.randn(8, generator=g) * 0.1]
+    w = torch.randn(d, (d + 3) * 8, generator=g) * ((d + 3) * 8) ** -0.5
+    b = torch.randn(d, generator=g) * 0.1
+    be = ops.backend()
+    assert be.pointconv_linear_supported(d, d) and not be.pointconv_linear_supported(128, 128) and not be.pointconv_linear_supported(32, 64)
+    assert be.pointconv_linear_supported(d, d, rows=B * s) == (B * s >= 16384)
+    want = OracleBackend().pointconv_linear(xyz, new_xyz, pts, idx, *wn, w, b, 0.1)
+    dev = [t.to(DEV) for t in (xyz, new_xyz, pts, idx, *wn, w, b)]
+    got = be.pointconv_linear(*dev, 0.1)
+    assert got.shape == (B, s, d)
+    two = be.linear(be.pointconv_agg(*dev[:-2]), dev[-2], dev[-1], 0.1)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-4)
+    if B * s >= 16384:
+        assert torch.equal(got, two)
+    else:
+        torch.testing.assert_close(got, two, rtol=1e-5, atol=2e-5)   # same split-bf16 arithmetic, K summed in four parts there
+    assert torch.equal(got, be.pointconv_linear(*dev, 0.1, packed=be.pointconv_linear_pack(dev[-2], dev[-1])))  # deterministic
+
+
 def test_compat_helpers_keep_reference_signatures():
     from mocopci_amd import compat
     xyz, new_xyz = cloud(95, 2, 700).to(DEV), cloud(96, 2, 300).to(DEV)
