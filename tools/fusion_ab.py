@@ -1,5 +1,5 @@
 import os, sys, torch, statistics
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mocopci_amd import ops, synth
 be = ops.backend()
 torch.manual_seed(0)
@@ -18,5 +18,5 @@ def t(fn, reps=5):
         s.record(); fn(); e.record(); torch.cuda.synchronize(); v.append(s.elapsed_time(e))
     return statistics.median(v)
 out = be.fusion_mlp(p1, p2, idx, *ws)
-print(os.environ.get("MCP_FUSION_F32_MFMA", "0"), "fusion 24x8192: %.3f ms" % t(lambda: be.fusion_mlp(p1, p2, idx, *ws)))
-torch.save(out.cpu(), "/root/repo/gpurun_out/fus_%s.pt" % os.environ.get("MCP_FUSION_F32_MFMA", "0"))
+tag = os.path.basename(os.environ.get("MCP_HIP_LIB", "shipped")).replace(".so", "") + "_f32" * (os.environ.get("MCP_FUSION_F32_MFMA", "0") == "1")
+print(tag, "fusion 24x8192: %.3f ms" % t(lambda: be.fusion_mlp(p1, p2, idx, *ws), reps=15), " checksum %.9g" % float(out.double().sum()), flush=True)
