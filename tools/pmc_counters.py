@@ -29,7 +29,7 @@ FAMILIES = {  # name -> kernel-name substrings
     "knn_cosine": ("knn_cosine_kernel",),
     "fusion": ("fusion_kernel", "fusion_split_kernel"),
     "cross": ("cross_kernel",),
-    "pointconv": ("pointconv_agg_kernel",),
+    "pointconv": ("pointconv_agg_kernel", "pointconv_agg_lowlevel_kernel", "pointconv_linear_kernel"),
     "attention": ("attention_small_kernel", "attention_wide_kernel", "attention_kernel"),
     "attention_small": ("attention_small_kernel",),
     "attention_wide": ("attention_wide_kernel",),
