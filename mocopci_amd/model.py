@@ -269,17 +269,32 @@ class MoCoPCI(nn.Module):
         keep = torch.empty(x.shape[:2] + (1,) * (x.dim() - 2), device=x.device, dtype=x.dtype).bernoulli_(1.0 - p)
         return x * (keep / (1.0 - p))
 
+    CHECKPOINT_BYTES = 1 << 30  # net.train() forwards: unfused blocks whose intermediates exceed this are recomputed in the backward, in chunks of about this size
+
     def attend(self, q, kv, heads, scale=None):
-        """softmax(q k^T scale) v per head; with attention dropout (net.train()) the probabilities are materialised."""
+        """softmax(q k^T scale) v per head; with attention dropout (net.train()) the probabilities are materialised -- 10.7 GB per
+        tensor at level 1 of the B = 8, N = 8192 step, so large calls run in chunks of batch elements under
+        torch.utils.checkpoint: nothing of size heads x Nq x Nk outlives a chunk, the backward rebuilds one chunk at a time (the
+        dropout masks come back through the generator state the checkpoint restores)."""
         p = self._mode[1] if self._mode is not None else 0.0
         if p <= 0.0:
             return ops.backend().attention(q, kv, heads, scale=scale)
         BF, Nq, C = q.shape
         Nk, hd = kv.shape[1], C // heads
-        qh = q.reshape(BF, Nq, heads, hd).permute(0, 2, 1, 3)
-        kvh = kv.reshape(BF, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
-        attn = torch.softmax((qh @ kvh[0].transpose(-2, -1)) * (hd ** -0.5 if scale is None else scale), dim=-1)
-        return (F.dropout(attn, p, training=True) @ kvh[1]).permute(0, 2, 1, 3).reshape(BF, Nq, C)
+        sc = hd ** -0.5 if scale is None else scale
+
+        def dense(q_, kv_):
+            n = q_.shape[0]
+            qh = q_.reshape(n, Nq, heads, hd).permute(0, 2, 1, 3)
+            kvh = kv_.reshape(n, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+            attn = torch.softmax((qh @ kvh[0].transpose(-2, -1)) * sc, dim=-1)
+            return (F.dropout(attn, p, training=True) @ kvh[1]).permute(0, 2, 1, 3).reshape(n, Nq, C)
+        per_element = heads * Nq * Nk * 4
+        if BF * per_element <= self.CHECKPOINT_BYTES or not torch.is_grad_enabled():
+            return dense(q, kv)
+        from torch.utils.checkpoint import checkpoint
+        step = max(1, self.CHECKPOINT_BYTES // per_element)
+        return torch.cat([checkpoint(dense, q[i:i + step], kv[i:i + step], use_reentrant=False) for i in range(0, BF, step)], dim=0)
 
     # ---- point-set layers ---------------------------------------------------------------
     def pointconv(self, prefix, s_xyz, new_xyz, s_points, nsample=32, idx=None):
@@ -935,16 +950,54 @@ class MoCoPCI(nn.Module):
         """fusion (mocopci.py:810-819) in a net.train() forward: the three Conv2d + BatchNorm2d(eps 1e-3) + ReLU layers with BATCH
         statistics, so nothing can be folded and the layers run unfused on the gathered (B,N,64,.) tensor.  The batch holds
         `calls` consecutive reference calls (the three interpolated frames, mocopci.py:1046-1051), each normalised with its own
-        statistics, running estimates updated call by call."""
+        statistics, running estimates updated call by call.  Large inputs (the B = 8, N = 8192 step keeps 37 GiB of layer
+        outputs alive otherwise) run call by call under torch.utils.checkpoint: a call's layers are rebuilt in the backward, one
+        call at a time; the running statistics are updated here, outside the recomputed function, from the statistics it returns."""
         m = "multi_frame_inference.conv."
-        nb = ops.backend().group_rows(p2, grad.whole(idx))                         # (B,N,64,3)
-        resi = nb - p1.unsqueeze(2)
-        x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)
-        for ci, bi in ((0, 1), (3, 4), (6, 7)):
-            x = F.linear(x, self.W(m + str(ci)), self.Bv(m + str(ci)))
-            x = torch.relu(self.bn_batch(x.reshape(calls, -1, x.shape[-1]), m + str(bi), 1e-3).reshape(x.shape))
-        wgt = torch.softmax(x.max(dim=-1)[0], dim=-1)
-        return torch.sum(wgt.unsqueeze(-1) * nb, dim=2)
+        layers = ((0, 1), (3, 4), (6, 7))
+        idx = grad.whole(idx)
+        if p1.shape[0] * p1.shape[1] * idx.shape[-1] * 128 * 4 <= self.CHECKPOINT_BYTES or not torch.is_grad_enabled():
+            nb = ops.backend().group_rows(p2, idx)                                    # (B,N,64,3)
+            resi = nb - p1.unsqueeze(2)
+            x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)
+            for ci, bi in layers:
+                x = F.linear(x, self.W(m + str(ci)), self.Bv(m + str(ci)))
+                x = torch.relu(self.bn_batch(x.reshape(calls, -1, x.shape[-1]), m + str(bi), 1e-3).reshape(x.shape))
+            wgt = torch.softmax(x.max(dim=-1)[0], dim=-1)
+            return torch.sum(wgt.unsqueeze(-1) * nb, dim=2)
+        from torch.utils.checkpoint import checkpoint
+        P = self._params()
+        G = ops.backend().group_rows
+        params = [t for ci, bi in layers for t in (self.W(m + str(ci)), self.Bv(m + str(ci)), P[m + f"{bi}.weight"], P[m + f"{bi}.bias"])]
+
+        def one_call(p1c, p2c, idxc, *wb):  # pure: reads nothing but its arguments, so the backward can run it again
+            nb = G(p2c, idxc)
+            resi = nb - p1c.unsqueeze(2)
+            x = torch.cat([resi, torch.norm(resi, dim=-1, keepdim=True)], dim=-1)
+            stats = []
+            for i in range(3):
+                w, b, gamma, beta = wb[4 * i:4 * i + 4]
+                x = F.linear(x, w, b)
+                flat = x.reshape(-1, x.shape[-1])
+                mean, var = flat.mean(dim=0), flat.var(dim=0, unbiased=False)
+                stats += [mean.detach(), var.detach()]
+                x = torch.relu((x - mean) * (gamma * torch.rsqrt(var + 1e-3)) + beta)
+            wgt = torch.softmax(x.max(dim=-1)[0], dim=-1)
+            return (torch.sum(wgt.unsqueeze(-1) * nb, dim=2), *stats)
+        per = p1.shape[0] // calls
+        outs = []
+        for c in range(calls):
+            sl = slice(c * per, (c + 1) * per)
+            out, *stats = checkpoint(one_call, p1[sl], p2[sl], idx[sl], *params, use_reentrant=False)
+            outs.append(out)
+            n = per * p1.shape[1] * idx.shape[-1]
+            with torch.no_grad():
+                for i, (ci, bi) in enumerate(layers):
+                    rm, rv, mom = P[m + f"{bi}.running_mean"], P[m + f"{bi}.running_var"], self.BN_MOMENTUM
+                    rm.mul_(1.0 - mom).add_(stats[2 * i], alpha=mom)
+                    rv.mul_(1.0 - mom).add_(stats[2 * i + 1], alpha=mom * n / (n - 1))
+                    P[m + f"{bi}.num_batches_tracked"].add_(1)
+        return torch.cat(outs, dim=0)
 
     # ---- decoder ------------------------------------------------------------------------
     def run_decoder(self, pcs, feats, B, train=False):

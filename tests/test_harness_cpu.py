@@ -84,6 +84,39 @@ def test_train_mode_batch_statistics_match_the_reference(oracle_backend, capsys)
     hc.run_train_mode_check("cpu", report)
 
 
+def test_checkpointed_train_mode_blocks_match_the_direct_form(oracle_backend):
+    """net.train() forwards recompute their two largest unfused blocks in the backward once they exceed MoCoPCI.CHECKPOINT_BYTES (the
+    fusion MLP with batch statistics call by call, dropout attention in chunks of batch elements): with the threshold forced to
+    64 KiB a whole training step (N = 512) gives the loss, the parameter gradients, the running statistics and the update counters
+    of the direct form.  (Attention dropout at 1e-12 keeps every probability and scales by 1.0f: the chunked path runs, the masks
+    cannot differ.)"""
+    from mocopci_amd import synth, training
+    from mocopci_amd.model import MoCoPCI
+    x1, x2, gt = synth.make_batch(3, 1, 512)
+    gtc = [g.transpose(1, 2).contiguous() for g in gt]
+
+    def step(limit):
+        net = hc.build_model("cpu")
+        net.train()
+        net.drop_rate, net.attn_drop_rate, net.drop_path_rate = 0.0, 1e-12, 0.0
+        net.CHECKPOINT_BYTES = limit
+        torch.manual_seed(11)
+        frames_f, frames_b, gt_frame, out = net(x1, x2, gtc, None, True)
+        loss, _ = training.multiscale_loss(frames_f, frames_b, gt_frame, out, gtc)
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}, net.state_dict()
+    l0, g0, s0 = step(MoCoPCI.CHECKPOINT_BYTES)
+    l1, g1, s1 = step(1 << 16)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert set(g0) == set(g1)
+    a, b = torch.cat([g0[n].flatten() for n in sorted(g0)]), torch.cat([g1[n].flatten() for n in sorted(g0)])
+    assert float((a - b).norm() / a.norm()) <= 1e-5
+    for n in hc.TRAIN_STATS:
+        assert int(s0[n + ".num_batches_tracked"]) == int(s1[n + ".num_batches_tracked"]), n
+        for leaf in (".running_mean", ".running_var"):
+            torch.testing.assert_close(s1[n + leaf], s0[n + leaf], rtol=1e-5, atol=1e-6)
+
+
 def test_inference_cache_follows_in_place_parameter_updates(oracle_backend):
     """Folded BatchNorms / packed operands are cached for inference; an in-place update of a parameter or buffer (optimizer step,
     running statistics) must invalidate them: the module then answers exactly like a fresh module loaded with the new state."""
