@@ -98,6 +98,7 @@ class MoCoPCI(nn.Module):
     drop_path_rate = 0.04   # stochastic depth of Multi_Frame_Att's two residual branches (Cross_Frame_Att: 0)
     BN_MOMENTUM = 0.1       # nn.BatchNorm default
     PAIR_CFA = True         # inference: cross_block3 evaluated once for both decoder directions (it is symmetric in its two frames)
+    LANE_MAP = None         # side lanes folded onto fewer HIP streams, e.g. (0, 1, 1, 1, 0, 0) (experiments with several caller streams: tools/two_stream.py)
     FUSE_POINTCONV = True  # PointConv's Linear inside the grouped kernel where it is built for the shape (A/B switch)
     FOLD_EI = True          # inference: EI cross-formers in their folded 9-launch form (A/B: tools/step_time.py net.FOLD_EI=0)
 
@@ -340,6 +341,8 @@ class MoCoPCI(nn.Module):
         independent.  CPU backends run inline."""
         if device.type != "cuda" or self._live is not None:  # a training forward runs on one stream (autograd replays it in order)
             return None
+        if self.LANE_MAP is not None:
+            which = self.LANE_MAP[which]
         key = (device.index, torch.cuda.current_stream(device).stream_id, which)
         sides = self.__dict__.setdefault("_sides", {})
         if key not in sides:
