@@ -280,6 +280,7 @@ __global__ __launch_bounds__(8 * D) __attribute__((amdgpu_waves_per_eu(D == 32 ?
     using C = FusedCfg<D, NT>;
     constexpr int THREADS = C::THREADS, NCH = C::NCH, KP = C::KP, KTOT = C::KTOT, D4 = D / 4, XP = C::XP;
     constexpr int CF = NT * 2 * 3 * 64 * 4;  // floats per chunk of the weight image (chunk_floats(NT) of linear.hip)
+    constexpr int UNR = D == 32 ? 4 : 2;     // neighbour-loop unrolling: D = 64 runs at 128 VGPRs (two 512-thread workgroups per CU), deeper unrolling spills there
     extern __shared__ __attribute__((aligned(16))) float flds[];
     float(*wl)[K][WN] = reinterpret_cast<float(*)[K][WN]>(flds);                               // [FPPB][K][WN]
     float(*gx)[K][3] = reinterpret_cast<float(*)[K][3]>(flds + FPPB * K * WN);                 // [FPPB][K][3]
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(8 * D) __attribute__((amdgpu_waves_per_eu(D == 32 ?
         if (p0 + pl < total) {
             const long long bb = mcp_div(p0 + pl, s, f32);
             const float *fb = s_points + (long long)bb * n * D + c4 * 4;
-#pragma unroll(D == 32 ? 4 : 2)  // D = 64 runs at 128 VGPRs (two 512-thread workgroups per CU): deeper unrolling spills there
+#pragma unroll UNR
             for (int k = 0; k < K; ++k) {
                 const float4 f = *reinterpret_cast<const float4 *>(off32 ? fb + (unsigned)il[pl][k] * (unsigned)D : fb + (long long)il[pl][k] * D);
                 const float4 wa = *reinterpret_cast<const float4 *>(&wl[pl][k][0]);
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(8 * D) __attribute__((amdgpu_waves_per_eu(D == 32 ?
         }
         const int xl = tid / 3, xc = tid - xl * 3;  // the three coordinate channels of every point: threads 0..95
         if (tid < FPPB * 3 && p0 + xl < total) {
-#pragma unroll(D == 32 ? 4 : 2)
+#pragma unroll UNR
             for (int k = 0; k < K; ++k) {
                 const float f = gx[xl][k][xc];
                 const float4 wa = *reinterpret_cast<const float4 *>(&wl[xl][k][0]);
