@@ -99,6 +99,7 @@ class MoCoPCI(nn.Module):
     BN_MOMENTUM = 0.1       # nn.BatchNorm default
     PAIR_CFA = True         # inference: cross_block3 evaluated once for both decoder directions (it is symmetric in its two frames)
     LANE_MAP = None         # side lanes folded onto fewer HIP streams, e.g. (0, 1, 1, 1, 0, 0) (experiments with several caller streams: tools/two_stream.py)
+    SIDE_PROJECTIONS = True # decoder levels 2 / 1: the feature-only chain in front of Multiframe_Attention on a side lane (A/B switch)
     FUSE_POINTCONV = True  # PointConv's Linear inside the grouped kernel where it is built for the shape (A/B switch)
     FOLD_EI = True          # inference: EI cross-formers in their folded 9-launch form (A/B: tools/step_time.py net.FOLD_EI=0)
 
@@ -506,6 +507,11 @@ class MoCoPCI(nn.Module):
         idx3, w3 = cache[key]
         return be.interp3_apply(feat, idx3, w3)
 
+    def interp_prepare(self, dense, sparse, cache, key):
+        """Make the keyed 3-NN search of interp() now, on the current stream (a side lane is about to read it as well)."""
+        if key not in cache:
+            cache[key] = ops.backend().interp3_search(dense, sparse)
+
     def interp_flows(self, dense, sparse, flows, cache, key):
         """The three per-frame flow upsamples (mocopci.py:870-878, :936-944) as ONE interpolation: flows (B,3,S,3) are
         laid side by side as 9 channels (same 3-NN and weights for all of them).  Returns them stacked frame-major,
@@ -799,14 +805,23 @@ class MoCoPCI(nn.Module):
                                                self.time_code(self.T_B, dim, device).expand(B, -1, -1)], dim=0).unsqueeze(2).contiguous()
         return self._time_cache[key]
 
-    def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None, idx_c12=None):
-        """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C)."""
+    def mfa_projections(self, prefix, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1):
+        """The four cross_t11 / cross_t22 projections of Multiframe_Attention's concatenated features (mocopci.py:186-190):
+        (t11 of set 1, t22 of set 2, t11 of set 2, t22 of set 1).  They read features only."""
         c1, c2 = (f1_0, f1_1, f1_new), (f2_0, f2_1, f2_new)
         if not ops.backend().linear_supported(list(c1), self.W(prefix + ".bid.cross_t11").shape[0], few_rows=self._live is None):
             c1, c2 = torch.cat(c1, dim=-1), torch.cat(c2, dim=-1)  # library path: concatenate once, both projections read it
+        b = prefix + ".bid"
+        return self.lin(c1, b + ".cross_t11"), self.lin(c2, b + ".cross_t22"), self.lin(c2, b + ".cross_t11"), self.lin(c1, b + ".cross_t22")
+
+    def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None, idx_c12=None,
+                             projections=None):
+        """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C).  projections: key of an Early result whose last four
+        members are mfa_projections(...) -- the decoder then ran that feature-only chain on a side lane beside the warp / search chain
+        below, which reads only coordinates and flows (f1_new / f2_new are not read here in that case)."""
         b, fe = prefix + ".bid", prefix + ".fe"
-        t11_1, t22_2 = self.lin(c1, b + ".cross_t11"), self.lin(c2, b + ".cross_t22")
-        t11_2, t22_1 = self.lin(c2, b + ".cross_t11"), self.lin(c1, b + ".cross_t22")
+        if projections is None:
+            t11_1, t22_2, t11_2, t22_1 = self.mfa_projections(prefix, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1)
         bid_mlp = [b + ".mlp.0"]
         fe_mlp = [fe + ".mlp.0"]
         fes = []
@@ -845,6 +860,8 @@ class MoCoPCI(nn.Module):
             # kernel reads batch element b of them from element b mod 2B through a batch map instead of R copies
             members = need if sel is not None else list(range(R * B2))
             bmap = self.batch_map(tuple(i % B2 for i in members), dev)
+            if projections is not None:
+                t11_1, t22_2, t11_2, t22_1 = self._early.get(projections)[-4:]
             n1a = self.cross(pc1r, pc2w, t11_1, t22_2, None, None, b + ".pos", bid_mlp, True, idx_c12, bmap=bmap, shared=7)
             n2a = self.cross(pc2w, pc1r, t11_2, t22_1, None, None, b + ".pos", bid_mlp, True, idx_c21, bmap=bmap, shared=7)
             fea = self.cross(pc1r, pc2w, self.lin(n1a, fe + ".conv1"), self.lin(n2a, fe + ".conv2"), None, None, fe + ".pos", fe_mlp,
@@ -1069,6 +1086,22 @@ class MoCoPCI(nn.Module):
             new3 = torch.baddbmm(bt, new3.reshape(2, -1, new3.shape[-1]), wt).reshape(new3.shape[0], new3.shape[1], -1)
         else:
             new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
+        # Feature-only chains (upsampled features -> deconv -> the four projections of the next Multiframe_Attention) run on the level's
+        # feature lane -- idle since the encoder -- beside the main stream's coordinate chain (cross_block3 / flow upsampling / warp /
+        # searches): both are rows of small launches that leave the chip mostly empty.  The 3-NN search both sides interpolate with is
+        # made first, on this stream.
+        side = self._live is None and self.SIDE_PROJECTIONS and self.side_stream(dev, 2) is not None
+        if side:
+            self.interp_prepare(pcs[2], pcs[3], cache, "32")
+            fus[2] = early.get(("fus", 2))
+            f2o = feats_o[2]
+            def chain2():
+                f = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
+                return self.mfa_projections(m + "multi_frame_up_2", f, sw(f), feats[2], fus[2], f2o, fus[2])
+            early.launch(("mfa_proj", 2), chain2, lane=2)
+            f_l3_2 = None
+        else:
+            f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
         # cross_block3, both directions at once (mocopci.py:853-856)
         self._mark("cross3 done")
         if self._live is None and self.PAIR_CFA:
@@ -1076,7 +1109,6 @@ class MoCoPCI(nn.Module):
         else:
             xs = torch.stack([new3, sw(new3)], dim=1)                              # (2B,2,N3,C)
             _, frame3s = self.cross_frame_att(m + "cross_block3", xs, feats=False)  # (2B,3,N3,3)
-        f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
 
         # Which level-1 flows are read: l0 (below) uses, of the 2B samples x 3 frames, the forward branch's frames 0,1 and
         # the backward branch's frame 0.  (Their flow embeddings also need each frame's attention partner f <-> 2-f, so
@@ -1090,25 +1122,34 @@ class MoCoPCI(nn.Module):
         te = self.time_pair(B, C, dev)                                              # (2B,5,1,C)
         fus[2] = early.get(("fus", 2))
         self._mark("got early fus2/cos2")
-        frame2s, n1_2, n2_2 = self.multiframe_attention(m + "multi_frame_up_2", pcs[2], pcs_o[2], f_l3_2, sw(f_l3_2), feats[2], fus[2],
-                                                        feats_o[2], fus[2], ups, te, idx_c12=early.get(("cos", 2)))  # (2B,3,N2,3)
+        frame2s, n1_2, n2_2 = self.multiframe_attention(m + "multi_frame_up_2", pcs[2], pcs_o[2], f_l3_2, None if side else sw(f_l3_2), feats[2],
+                                                        fus[2], feats_o[2], fus[2], ups, te, idx_c12=early.get(("cos", 2)),
+                                                        projections=("mfa_proj", 2) if side else None)  # (2B,3,N2,3)
         # l2 -> l1 (mocopci.py:920-927): the forward branch upsamples (feat1_new_f -> pc1, feat2_new_f -> pc2),
         # the backward branch (feat1_new_b -> pc1, feat2_new_b -> pc2) where *_b come from the swapped call.
-        f1_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n1_2[:B], n2_2[:B]], 0), cache, "21"), m + "deconv2_1")
-        f2_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n2_2[B:], n1_2[B:]], 0), cache, "21"), m + "deconv2_1")
-        # forward call gets (feat1_l2_1_f, feat2_l2_1_f); backward call gets (feat2_l2_1_b, feat1_l2_1_b)
-        f_up_1 = torch.cat([f1_up[:B], f2_up[B:]], dim=0)
-        f_up_1_o = torch.cat([f1_up[B:], f2_up[:B]], dim=0)
+        def upsampled1():
+            f1_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n1_2[:B], n2_2[:B]], 0), cache, "21"), m + "deconv2_1")
+            f2_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n2_2[B:], n1_2[B:]], 0), cache, "21"), m + "deconv2_1")
+            # forward call gets (feat1_l2_1_f, feat2_l2_1_f); backward call gets (feat2_l2_1_b, feat1_l2_1_b)
+            return torch.cat([f1_up[:B], f2_up[B:]], dim=0), torch.cat([f1_up[B:], f2_up[:B]], dim=0)
+        fus[1] = early.get(("fus", 1))
+        if side:
+            self.interp_prepare(pcs[1], pcs[2], cache, "21")
+            f1o = feats_o[1]
+            early.launch(("mfa_proj", 1), lambda: self.mfa_projections(m + "multi_frame_up_1", *upsampled1(), feats[1], fus[1], f1o, fus[1]), lane=1)
+            f_up_1 = f_up_1_o = None
+        else:
+            f_up_1, f_up_1_o = upsampled1()
         ups = self.interp_flows(pcs[1], pcs[2], frame2s, cache, "21")
         C = feats[1].shape[-1]
         te = self.time_pair(B, C, dev)
         # l0 (mocopci.py:997-1053).  Output frames 0,1 use the forward branch (flow index i on frame 1);
         # frame 2 uses the backward branch: up_frame0_lst_b[2] = upsample(frame1s_b[:, 3-2-1]).  Of the level-1 flows
         # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.
-        fus[1] = early.get(("fus", 1))
         self._mark("level2 done, got early fus1")
         frame1s = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
-                                            feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=early.get(("cos", 1)))[0].contiguous()
+                                            feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=early.get(("cos", 1)),
+                                            projections=("mfa_proj", 1) if side else None)[0].contiguous()
         pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
         f0 = torch.cat([feats[0][:B], feats[0][:B], feats[0][B:]], dim=0)
         # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
