@@ -1062,12 +1062,19 @@ class MoCoPCI(nn.Module):
         # level-0 interpolation search were issued by the encoder as soon as their inputs existed (Early)
         # (level 3's own are needed right here, so they run inline)
         self._mark("dec start")
+        up43 = lambda: self.conv1d_block(self.interp(pcs[3], pcs[4], feats[4], cache, "43"), m + "deconv4_3")   # l4 -> l3 (mocopci.py:842-845)
+        side3 = self._live is None and self.SIDE_PROJECTIONS and self.side_stream(dev, 3) is not None
+        if side3:
+            # beside the EI cross-former of level 3 (a row of small launches on this stream), on level 3's own lane: the upsampled level-4
+            # features and cross3's feature-cosine search -- both read encoder outputs only
+            f3o = feats_o[3]
+            early.launch(("up43",), up43, lane=3)
+            early.launch(("cos", 3), lambda: ops.backend().knn_cosine(feats[3], f3o, 16), lane=3)
         f3 = self.ei_crossformer(m + "ei3", feats[3][:B], feats[3][B:], stacked=feats[3])
         fus = [None, None, None, torch.cat([f3, f3], dim=0)]
 
         self._mark("ei3 done")
-        # l4 -> l3 (mocopci.py:842-845)
-        f_l4_3 = self.conv1d_block(self.interp(pcs[3], pcs[4], feats[4], cache, "43"), m + "deconv4_3")
+        f_l4_3 = early.get(("up43",)) if side3 else up43()
         c3 = torch.cat([feats[3], fus[3], f_l4_3], dim=-1)                         # (2B,256,576)
         # cross3 (pointconv_util.py:783-791): rows [:B] give feat1_new, rows [B:] give feat2_new
         x = m + "cross3"
@@ -1075,8 +1082,14 @@ class MoCoPCI(nn.Module):
             # points2 = cross_t22 of the OTHER frame's concatenation: the kernel reads batch element b of the projection from element
             # (b + B) mod 2B through its batch map instead of a swapped copy of the 576-wide input
             swap_map = self.batch_map(tuple((i + B) % (2 * B) for i in range(2 * B)), dev)
-            new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(c3, x + ".cross_t22"), feats[3],
-                              feats_o[3], x + ".pos1", [x + ".mlp1.0"], False, bmap=swap_map, shared=2)
+            if side3:  # the two 576 -> 256 projections (library GEMMs, 60 us each at 4096 rows) side by side
+                early.launch(("t22", 3), lambda: self.lin(c3, x + ".cross_t22"), lane=3)
+                t11_3 = self.lin(c3, x + ".cross_t11")
+                t22_3, cos3 = early.get(("t22", 3)), early.get(("cos", 3))
+            else:
+                t11_3, t22_3, cos3 = self.lin(c3, x + ".cross_t11"), self.lin(c3, x + ".cross_t22"), None
+            new3 = self.cross(pcs[3], pcs_o[3], t11_3, t22_3, feats[3], feats_o[3], x + ".pos1", [x + ".mlp1.0"], False, idx_c=cos3,
+                              bmap=swap_map, shared=2)
         else:
             new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(sw(c3), x + ".cross_t22"), feats[3],
                               feats_o[3], x + ".pos1", [x + ".mlp1.0"], False)
