@@ -931,12 +931,13 @@ class MoCoPCI(nn.Module):
             return be.linear(feats, w, b, 1.0, None, packed=packed)
         return F.linear(feats, w, b)
 
-    def transformer_block(self, prefix, feats, xyz, k=16, qkv=None):
+    def transformer_block(self, prefix, feats, xyz, k=16, qkv=None, idx=None):
         """TransformerBlock.forward (pointT_layer2.py:58-77): vector attention over the 16 nearest
         neighbours (direct squared distance; the reference's full argsort is replaced by the KNN kernel).
-        qkv: the packed (B,N,3C) projections when the caller already has them."""
+        qkv: the packed (B,N,3C) projections when the caller already has them; idx: likewise the neighbour lists."""
         be = ops.backend()
-        idx = be.knn(xyz, xyz, k, mode=ops.MCP_DIST_DIRECT)
+        if idx is None:
+            idx = be.knn(xyz, xyz, k, mode=ops.MCP_DIST_DIRECT)
         if qkv is None:
             qkv = self.qkv_projection(prefix, feats)
         C = feats.shape[-1]
@@ -1056,6 +1057,15 @@ class MoCoPCI(nn.Module):
                 return self.have[i]
         pcs_o, feats_o = _Other("swap_pc", pcs), _Other("swap_f", feats)
         cache = {}
+        side0 = self._live is None and self.SIDE_PROJECTIONS and not train and self.side_stream(dev, 1) is not None
+        if side0:
+            # level 0's stacked inputs (frames 1, 1, 2 for the three interpolated frames) read encoder outputs only: four copies made on
+            # the lane that produced the level-0 interpolation search, long before the main stream wants them
+            def rep0():
+                i3_, w3_ = early.get("i3_01")
+                r3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
+                return r3(pcs[0]), r3(feats[0]), r3(i3_), r3(w3_)
+            early.launch(("rep0",), rep0, lane=1)
 
         # EI cross-formers (mocopci.py:830-836): fusion features are shared by both frames
         # EI cross-formers (mocopci.py:830-836; fusion features shared by both frames), the feature-cosine searches and the
@@ -1163,12 +1173,14 @@ class MoCoPCI(nn.Module):
         frame1s = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
                                             feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=early.get(("cos", 1)),
                                             projections=("mfa_proj", 1) if side else None)[0].contiguous()
-        pc0 = torch.cat([pcs[0][:B], pcs[0][:B], pcs[0][B:]], dim=0)
-        f0 = torch.cat([feats[0][:B], feats[0][:B], feats[0][B:]], dim=0)
+        rep3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
         # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
         # (2B rows), its rows repeated for the 3B arrangement
-        i3, w3 = early.get("i3_01")
-        rep3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
+        if side0:
+            pc0, f0, i3r, w3r = early.get(("rep0",))
+        else:
+            pc0, f0 = rep3(pcs[0]), rep3(feats[0])
+            i3, w3 = early.get("i3_01")
         if train:
             # all six upsampled level-1 flows (mocopci.py:1011-1019): up_f[i] = upsample(frame1s_f[:, i]) on frame 1's points,
             # up_b[i] = upsample(frame1s_b[:, 2 - i]) on frame 2's points
@@ -1179,11 +1191,13 @@ class MoCoPCI(nn.Module):
             up_flow = torch.cat([up_f[0], up_f[1], up_b[2]], dim=0)
         else:
             flow_src = frame1s                                                     # (3B,N1,3): the three flows read below
-            up_flow = ops.backend().interp3_apply(flow_src, rep3(i3), rep3(w3))    # (3B,N,3)
+            up_flow = ops.backend().interp3_apply(flow_src, *((i3r, w3r) if side0 else (rep3(i3), rep3(w3))))    # (3B,N,3)
         self._mark("level1 done")
         warped = pc0 + up_flow
-        # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022)
-        wf = f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev)
+        # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022), then rlevel0
+        refine_feat = lambda: self.conv1d_block(f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev), m + "rlevel0")
+        if side0:  # read next by the refinement stage's PointConvD, after the sampling: beside the warped clouds' self search
+            early.launch(("wf",), refine_feat, lane=2)
         side = self.side_stream(dev, 5)  # NOT lane 0: the next batch's sampling pyramid is queued there (prefetch) and must not wait for this
         if side is not None:
             main = torch.cuda.current_stream(dev)
@@ -1196,7 +1210,7 @@ class MoCoPCI(nn.Module):
             sel.record_stream(main)
         else:
             down, sel = self.fps_gather(warped, 2048, return_idx=True)
-        wf = self.conv1d_block(wf, m + "rlevel0")
+        wf = None if side0 else refine_feat()
         idx_self = ops.backend().knn(warped, warped, 32)      # fusion's self search: independent of the refine branch
         if side is not None and defer:
             # The sampling (a 1.2-1.4 ms latency chain on 24 CUs) is on its way; whatever the caller enqueues on this stream before
@@ -1205,16 +1219,23 @@ class MoCoPCI(nn.Module):
             issued = torch.cuda.current_stream(dev)
             yield
             main = torch.cuda.current_stream(dev)
+            if side0:
+                wf = early.get(("wf",))
             if main != issued:  # finish(..., tail_stream=...): the tail runs on another stream than the part that produced these
                 for t_ in (warped, wf, idx_self, down, sel):
                     t_.record_stream(main)
             main.wait_event(done)
             be = ops.backend()
             early.launch("i3_refine", lambda: be.interp3_search(warped, down), lane=1)
+            if side0:  # the Point-Transformer's 16-NN search needs the sampled cloud only: beside PointConvD
+                down.record_stream(self.side_stream(dev, 2))
+                early.launch("knn_down", lambda: be.knn(down, down, 16, mode=ops.MCP_DIST_DIRECT), lane=2)
             dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel))
-            shape = self.transformer_block(m + "shape1", dfeat, down)
+            shape = self.transformer_block(m + "shape1", dfeat, down, idx=early.get("knn_down") if side0 else None)
             upf = be.interp3_apply(shape, *early.get("i3_refine"))
         elif side is not None:
+            if side0:
+                wf = early.get(("wf",))
             # same speculation as in the encoder: PointConvD of EVERY candidate centre and the Point-Transformer's four
             # per-point projections are computed while the sampling runs, the sampled rows are gathered afterwards
             be = ops.backend()
