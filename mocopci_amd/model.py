@@ -1197,6 +1197,7 @@ class MoCoPCI(nn.Module):
         # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022), then rlevel0
         refine_feat = lambda: self.conv1d_block(f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev), m + "rlevel0")
         if side0:  # read next by the refinement stage's PointConvD, after the sampling: beside the warped clouds' self search
+            f0.record_stream(self.side_stream(dev, 2))   # made on lane 1, read on lane 2
             early.launch(("wf",), refine_feat, lane=2)
         side = self.side_stream(dev, 5)  # NOT lane 0: the next batch's sampling pyramid is queued there (prefetch) and must not wait for this
         if side is not None:
