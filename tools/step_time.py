@@ -10,6 +10,8 @@ steps = 40
 for a in sys.argv[1:]:
     if a.startswith("--steps"):
         steps = int(a.split("=")[1])
+    elif a.startswith("net.LANE_MAP="):   # e.g. net.LANE_MAP=0,1,2,3,0,5: side lanes folded onto fewer HIP streams
+        MoCoPCI.LANE_MAP = tuple(int(t) for t in a.split("=")[1].split(","))
     elif a.startswith("net."):
         k, v = a[4:].split("=")
         setattr(MoCoPCI, k, type(getattr(MoCoPCI, k))(int(v)))
