@@ -48,7 +48,7 @@ PMC_STAMP = os.path.join(ROOT, "profiles", "r03_pmc_sources.json")  # sha256 of 
 
 NAMES = {
     "fps": "fps_spatial_kernel / fps_resident_kernel (mcp_furthest_point_sampling_ws)",
-    "knn": "knn_pruned / knn_queue / knn_small kernels (mcp_knn, mcp_knn_pruned)",
+    "knn": "knn_walk (K = 32) / knn_pruned (K <= 16) / knn_queue / knn_small kernels (mcp_knn, mcp_knn_pruned)",
     "knn_cosine": "knn_cosine_kernel (mcp_knn_cosine)",
     "fusion": "fusion_split_kernel (mcp_fusion)",
     "cross": "cross_kernel<64|128|256> (mcp_cross_volume)",

@@ -23,8 +23,8 @@ import sys
 
 FAMILIES = {  # name -> kernel-name substrings
     "fps": ("fps_spatial_kernel", "fps_resident_kernel", "fps_stream_kernel", "fps_tiled_kernel"),
-    "knn": ("knn_pruned_kernel", "knn_queue_kernel", "knn_small_kernel"),
-    "knn_pruned": ("knn_pruned_kernel",),
+    "knn": ("knn_walk_kernel", "knn_pruned_kernel", "knn_queue_kernel", "knn_small_kernel"),
+    "knn_pruned": ("knn_walk_kernel", "knn_pruned_kernel"),
     "build_cloud": ("build_cloud_kernel",),
     "knn_cosine": ("knn_cosine_kernel",),
     "fusion": ("fusion_kernel", "fusion_split_kernel"),
