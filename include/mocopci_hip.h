@@ -290,6 +290,11 @@ int mcp_linear_narrow(long long rows, int k, int n, const float *x, int x_stride
 int mcp_linear_pack(int n, int nseg, const int *k_seg, const float *w, const float *b, float *packed, mcp_stream_t stream);
 int mcp_linear(long long rows, int n, int nseg, const float *const *x, const int *x_stride, const int *k_seg, float slope,
                const float *packed, const float *res, int res_stride, float *out, int out_stride, mcp_stream_t stream);
+/* mcp_linear with the kernel chosen as for `policy_rows` rows (the few-row split-K form sums K in another order than the full-K
+ * form): a caller that computes a SUBSET of the rows of a tall product -- the sampled rows of a PointConvD whose every candidate
+ * row another code path computes (mocopci_amd/model.py: speculative / deferred forms of one forward) -- gets the same bits. */
+int mcp_linear_as(long long rows, long long policy_rows, int n, int nseg, const float *const *x, const int *x_stride, const int *k_seg,
+                  float slope, const float *packed, const float *res, int res_stride, float *out, int out_stride, mcp_stream_t stream);
 
 /* Fused two-layer per-point MLP (Mlp_T of Multi_Frame_Att, mocopci.py:1558-1565 inside :551-575, and the flow heads
  * trans_block / trans_block_2 -> mapping_xyz, :566-567 / :510-511):

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mcp_add_layernorm": [ctypes.c_longlong, _i, _p, ctypes.c_longlong, _p, ctypes.c_longlong, _p, _p, _p, _f, _p, ctypes.c_longlong, _p],
     "mcp_mfa_prepare": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "mcp_linear": [ctypes.c_longlong, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _p],
+    "mcp_linear_as": [ctypes.c_longlong, ctypes.c_longlong, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _p],
     "mcp_linear_narrow": [ctypes.c_longlong, _i, _i, _p, _i, _p, _p, _f, _p, _i, _p],
     "mcp_mlp2_packed_floats": [_i, _i, _i],
     "mcp_mlp2_pack": [_i, _i, _i, _p, _p, _p, _p, _p, _p],

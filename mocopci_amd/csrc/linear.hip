@@ -529,9 +529,9 @@ MCP_EXPORT int mcp_linear_pack(int n, int nseg, const int *k_seg, const float *w
     return mcp_launch_status();
 }
 
-MCP_EXPORT int mcp_linear(long long rows, int n, int nseg, const float *const *x, const int *x_stride, const int *k_seg, float slope,
-                          const float *packed, const float *res, int res_stride, float *out, int out_stride, mcp_stream_t stream) {
-    MCP_CHECK_ARGS(rows > 0 && x && x_stride && k_seg && packed && out);
+MCP_EXPORT int mcp_linear_as(long long rows, long long policy_rows, int n, int nseg, const float *const *x, const int *x_stride, const int *k_seg,
+                             float slope, const float *packed, const float *res, int res_stride, float *out, int out_stride, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(rows > 0 && policy_rows > 0 && x && x_stride && k_seg && packed && out);
     if (mcp_linear_packed_floats(n, nseg, k_seg) == 0) return MCP_ERR_UNSUPPORTED;
     Segs sg{};
     for (int i = 0; i < nseg; ++i) {
@@ -546,7 +546,7 @@ MCP_EXPORT int mcp_linear(long long rows, int n, int nseg, const float *const *x
     const int nt = (n + 31) / 32, total = count_chunks(nseg, k_seg);
     int rc;
     mcp_prof_begin(MCP_KERNEL_LINEAR, s);
-    if (rows < MCP_LINEAR_SPLITK_ROWS && total >= 4) {  // few rows: four waves split the K chunks of one 32-row tile
+    if (policy_rows < MCP_LINEAR_SPLITK_ROWS && total >= 4) {  // few rows: four waves split the K chunks of one 32-row tile
         rc = (nt & 1) ? launch_linear_splitk<1>(rows, n, nt, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s)
                       : launch_linear_splitk<2>(rows, n, nt, sg, nseg, total, slope, packed, res, res_stride, out, out_stride, s);
         mcp_prof_end(MCP_KERNEL_LINEAR, s);
@@ -563,4 +563,9 @@ MCP_EXPORT int mcp_linear(long long rows, int n, int nseg, const float *const *x
     }
     mcp_prof_end(MCP_KERNEL_LINEAR, s);
     return rc;
+}
+
+MCP_EXPORT int mcp_linear(long long rows, int n, int nseg, const float *const *x, const int *x_stride, const int *k_seg, float slope,
+                          const float *packed, const float *res, int res_stride, float *out, int out_stride, mcp_stream_t stream) {
+    return mcp_linear_as(rows, rows, n, nseg, x, x_stride, k_seg, slope, packed, res, res_stride, out, out_stride, stream);
 }

@@ -38,14 +38,24 @@ def leaky(x):
     return F.leaky_relu(x, LEAKY)
 
 
+class _Epoch:
+    """Assignment counter of ONE model (shared by the nodes of its parameter tree)."""
+    __slots__ = ("n",)
+
+    def __init__(self):
+        self.n = 0
+
+
 class _Node(nn.Module):
     """A node of the generated parameter tree.  Assigning a tensor to one of its attributes (net.x.weight = nn.Parameter(..),
-    load_state_dict(assign=True)) bumps a global epoch, which MoCoPCI's inference cache is keyed on beside the version counters."""
-    epoch = 0
+    load_state_dict(assign=True)) bumps the epoch of the model it belongs to, which that model's inference cache is keyed on beside
+    the version counters.  (Per model: constructing or editing another MoCoPCI leaves this one's cache alone.)"""
 
     def __setattr__(self, name, value):
         if isinstance(value, torch.Tensor):
-            _Node.epoch += 1
+            ref = self.__dict__.get("_epoch_ref")
+            if ref is not None:
+                ref.n += 1
         super().__setattr__(name, value)
 
 
@@ -105,6 +115,7 @@ class MoCoPCI(nn.Module):
 
     def __init__(self):
         super().__init__()
+        self.__dict__["_epoch_ref"] = _Epoch()
         with open(_SPEC_PATH) as fh:
             self._spec = json.load(fh)
         for name, meta in self._spec.items():
@@ -112,7 +123,9 @@ class MoCoPCI(nn.Module):
             node = self
             for p in parts[:-1]:
                 if p not in node._modules:
-                    node.add_module(p, _Node())
+                    child = _Node()
+                    child.__dict__["_epoch_ref"] = self.__dict__["_epoch_ref"]
+                    node.add_module(p, child)
                 node = getattr(node, p)
             t = torch.zeros(meta["shape"], dtype=_dtype(meta["dtype"]))
             if meta["buffer"]:
@@ -123,6 +136,13 @@ class MoCoPCI(nn.Module):
         self._live = None  # training forward: {name: live parameter / buffer}; derived tensors are then rebuilt, not cached
         self._mode = None  # training forward in net.train() mode: (drop, attn_drop, drop_path) -- BatchNorm then uses batch statistics
         self.eval()
+
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.Tensor):  # a tensor assigned on the root module itself
+            ref = self.__dict__.get("_epoch_ref")
+            if ref is not None:
+                ref.n += 1
+        super().__setattr__(name, value)
 
     def _mark(self, name):
         """Timeline marker (tools/step_sections.py sets self._marks = []): an event on the current stream; nothing otherwise."""
@@ -156,10 +176,11 @@ class MoCoPCI(nn.Module):
     def _state_version(self):
         """Changes whenever a parameter or buffer is written in place (optimizer.step(), a training forward's running statistics,
         copy_ / load) or REPLACED by another tensor (load_state_dict(assign=True), net.x.weight = nn.Parameter(...)) -- everything
-        cached from them (folded BatchNorms, packed kernel operands) is then stale (assignments bump _Node.epoch)."""
+        cached from them (folded BatchNorms, packed kernel operands) is then stale (assignments bump this model's epoch)."""
         ts = self.__dict__.get("_state_tensors")
-        if ts is None or ts[0] != _Node.epoch:  # the module tree is fixed after construction: walked again only after an assignment
-            ts = self.__dict__["_state_tensors"] = (_Node.epoch, [*self.parameters(), *self.buffers()])
+        epoch = self.__dict__["_epoch_ref"].n
+        if ts is None or ts[0] != epoch:  # the module tree is fixed after construction: walked again only after an assignment
+            ts = self.__dict__["_state_tensors"] = (epoch, [*self.parameters(), *self.buffers()])
         v = 0
         for t in ts[1]:
             v += t._version
@@ -202,16 +223,20 @@ class MoCoPCI(nn.Module):
     def Bv(self, name):
         return self._params().get(name + ".bias")
 
-    def lin(self, x, name, slope=1.0, res=None):
+    def lin(self, x, name, slope=1.0, res=None, like_rows=None):
         """Linear / 1x1 conv `name` over the last axis with a one-slope activation (1.0 = none) and a residual: ONE kernel
-        (ops.linear) where the backend takes the shape -- the tall per-point layers -- and the BLAS chain otherwise."""
+        (ops.linear) where the backend takes the shape -- the tall per-point layers -- and the BLAS chain otherwise.
+        like_rows: x holds SOME of the rows of a product that another form of the same forward computes in full (the sampled rows
+        of a PointConvD whose every candidate row the speculative form evaluates): take the kernel that product takes, so that both
+        forms return the same bits whatever the batch size (the few-row kernels sum K in another order)."""
         w, b = self.W(name), self.Bv(name)
         be = ops.backend()
         pieces = isinstance(x, (tuple, list))  # the pieces of a concatenation along the channel axis: read in place by the kernel
-        if be.linear_supported(list(x) if pieces else x, w.shape[0], few_rows=self._live is None):
+        like = {} if like_rows is None or self._live is not None else {"policy_rows": like_rows}
+        if be.linear_supported(list(x) if pieces else x, w.shape[0], few_rows=self._live is None, **like):
             ks = [t.shape[-1] for t in x] if pieces else [x.shape[-1]]
             packed = None if self._live is not None else self.derived(("lin_pack", be.name, name, tuple(ks)), lambda: be.linear_pack(w, b, ks))
-            return be.linear(list(x) if pieces else x, w, b, slope, res, packed=packed)
+            return be.linear(list(x) if pieces else x, w, b, slope, res, packed=packed, **like)
         if pieces:
             x = torch.cat(list(x), dim=-1)
         y = F.linear(x, w, b)
@@ -219,9 +244,9 @@ class MoCoPCI(nn.Module):
             y = F.leaky_relu(y, slope)
         return y if res is None else y + res
 
-    def conv1d_block(self, x, name):
+    def conv1d_block(self, x, name, like_rows=None):
         """Conv1d wrapper of the reference (mocopci.py:1111-1127): 1x1 conv + LeakyReLU(0.1)."""
-        return self.lin(x, name + ".composed_module.0", slope=LEAKY)
+        return self.lin(x, name + ".composed_module.0", slope=LEAKY, like_rows=like_rows)
 
     def bn_eval(self, x, name, eps):
         """BatchNorm in eval mode on a channel-last tensor: one fused multiply-add with cached (scale, shift)."""
@@ -299,22 +324,24 @@ class MoCoPCI(nn.Module):
         return torch.cat([checkpoint(dense, q[i:i + step], kv[i:i + step], use_reentrant=False) for i in range(0, BF, step)], dim=0)
 
     # ---- point-set layers ---------------------------------------------------------------
-    def pointconv(self, prefix, s_xyz, new_xyz, s_points, nsample=32, idx=None):
+    def pointconv(self, prefix, s_xyz, new_xyz, s_points, nsample=32, idx=None, like_rows=None):
         """PointConv / PointConvD body after sampling (mocopci.py:1315-1346, :1362-1396; group /
         group_query :1218-1266; WeightNet :1289-1300).  idx: the (B,S,nsample) neighbour lists when the caller
-        already has them (see sampled_neighbours)."""
+        already has them (see sampled_neighbours).  like_rows: the centres are a subset of that many candidate centres which
+        another form of the same forward evaluates all of (see lin): same kernels, same bits."""
         be = ops.backend()
         B, S, _ = new_xyz.shape
         if idx is None:
             idx = be.knn(new_xyz, s_xyz, nsample)
         wn = [t for i in range(3) for t in (self.W(f"{prefix}.weightnet.mlp_convs.{i}"), self.Bv(f"{prefix}.weightnet.mlp_convs.{i}"))]
         w, b = self.W(prefix + ".linear"), self.Bv(prefix + ".linear")
-        if self.FUSE_POINTCONV and self._live is None and be.pointconv_linear_supported(s_points.shape[-1], w.shape[0], idx.shape[-1], rows=B * S):
+        if self.FUSE_POINTCONV and self._live is None and be.pointconv_linear_supported(s_points.shape[-1], w.shape[0], idx.shape[-1],
+                                                                                        rows=B * S if like_rows is None else like_rows):
             # levels 0 / 1 and the refinement stage: the (B,S,(3+D)*8) aggregate never leaves the compute unit
             packed = self.derived(("lin_pack", be.name, prefix + ".linear", (w.shape[1],)), lambda: be.pointconv_linear_pack(w, b))
             return be.pointconv_linear(s_xyz, new_xyz, s_points.contiguous(), idx, *wn, w, b, LEAKY, packed=packed)
         agg = be.pointconv_agg(s_xyz, new_xyz, s_points.contiguous(), idx, *wn)      # (B,S,(3+D)*8)
-        return self.lin(agg, prefix + ".linear", slope=LEAKY)
+        return self.lin(agg, prefix + ".linear", slope=LEAKY, like_rows=like_rows)
 
     def fps_gather(self, xyz, npoint, return_idx=False):
         """furthest_point_sample + index_points_gather (mocopci.py:1378-1379)."""
@@ -437,8 +464,10 @@ class MoCoPCI(nn.Module):
         else:
             need(1)
             # level 1 searches the 32 nearest of pc1 = xyz[sel1] in xyz: rows of the level-0 self search
-            f1 = self.pointconv(p + "level1", xyz, pc1, f0_1, idx=self.sampled_neighbours(idx0, sel1))
-            f1 = self.conv1d_block(f1, p + "level1_0")
+            # (kernels as for all of xyz's rows: the speculative form above computes those, and both must give the same bits)
+            like = xyz.shape[0] * xyz.shape[1]
+            f1 = self.pointconv(p + "level1", xyz, pc1, f0_1, idx=self.sampled_neighbours(idx0, sel1), like_rows=like)
+            f1 = self.conv1d_block(f1, p + "level1_0", like_rows=like)
         B = xyz.shape[0] // 2
         d = "multi_frame_inference."
         swap = lambda t: torch.cat([t[B:], t[:B]], dim=0)
@@ -917,7 +946,7 @@ class MoCoPCI(nn.Module):
         _, frames = self.multi_frame_att(prefix + ".cross_block", x, feats=False)  # (B,3,N,3)
         return frames, n1, n2
 
-    def qkv_projection(self, prefix, feats):
+    def qkv_projection(self, prefix, feats, like_rows=None):
         """TransformerBlock's x = fc1(features); q, k, v = w_qs(x), w_ks(x), w_vs(x) (pointT_layer2.py:62-66; the three
         projections have no bias and nothing else reads x) as ONE (C -> 3C) affine map: W = [Wq; Wk; Wv] W1, b = [..] b1.
         Returns the packed (B,N,3C) tensor [q | k | v]."""
@@ -926,12 +955,13 @@ class MoCoPCI(nn.Module):
             return (w3 @ self.W(prefix + ".fc1")).contiguous(), (w3 @ self.Bv(prefix + ".fc1")).contiguous()
         w, b = self.derived(("qkv_fold", prefix), fold)
         be = ops.backend()
-        if be.linear_supported(feats, w.shape[0], few_rows=self._live is None):  # tall inputs: the fused per-point Linear (67 vs 86 us at 196608 rows)
+        like = {} if like_rows is None or self._live is not None else {"policy_rows": like_rows}
+        if be.linear_supported(feats, w.shape[0], few_rows=self._live is None, **like):  # tall inputs: the fused per-point Linear (67 vs 86 us at 196608 rows)
             packed = None if self._live is not None else self.derived(("qkv_pack", be.name, prefix), lambda: be.linear_pack(w, b, [feats.shape[-1]]))
-            return be.linear(feats, w, b, 1.0, None, packed=packed)
+            return be.linear(feats, w, b, 1.0, None, packed=packed, **like)
         return F.linear(feats, w, b)
 
-    def transformer_block(self, prefix, feats, xyz, k=16, qkv=None, idx=None):
+    def transformer_block(self, prefix, feats, xyz, k=16, qkv=None, idx=None, like_rows=None):
         """TransformerBlock.forward (pointT_layer2.py:58-77): vector attention over the 16 nearest
         neighbours (direct squared distance; the reference's full argsort is replaced by the KNN kernel).
         qkv: the packed (B,N,3C) projections when the caller already has them; idx: likewise the neighbour lists."""
@@ -939,7 +969,7 @@ class MoCoPCI(nn.Module):
         if idx is None:
             idx = be.knn(xyz, xyz, k, mode=ops.MCP_DIST_DIRECT)
         if qkv is None:
-            qkv = self.qkv_projection(prefix, feats)
+            qkv = self.qkv_projection(prefix, feats, like_rows=like_rows)
         C = feats.shape[-1]
         w = [t for n in (".fc_delta.0", ".fc_delta.2", ".fc_gamma.0", ".fc_gamma.2") for t in (self.W(prefix + n), self.Bv(prefix + n))]
         packed = None if self._live is not None else self.derived(("ptblock_pack", be.name, prefix), lambda: be.ptblock_pack(*w))
@@ -1231,8 +1261,9 @@ class MoCoPCI(nn.Module):
             if side0:  # the Point-Transformer's 16-NN search needs the sampled cloud only: beside PointConvD
                 down.record_stream(self.side_stream(dev, 2))
                 early.launch("knn_down", lambda: be.knn(down, down, 16, mode=ops.MCP_DIST_DIRECT), lane=2)
-            dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel))
-            shape = self.transformer_block(m + "shape1", dfeat, down, idx=early.get("knn_down") if side0 else None)
+            like = warped.shape[0] * warped.shape[1]   # kernels as for every candidate centre: what the speculative form below computes
+            dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel), like_rows=like)
+            shape = self.transformer_block(m + "shape1", dfeat, down, idx=early.get("knn_down") if side0 else None, like_rows=like)
             upf = be.interp3_apply(shape, *early.get("i3_refine"))
         elif side is not None:
             if side0:
@@ -1280,7 +1311,9 @@ class MoCoPCI(nn.Module):
         k+1 while batch k is still being computed (forward(then_prefetch=...) does so right after batch k's encoder is enqueued),
         so the sampling chains run under batch k's decoder instead of stalling batch k+1's encoder.  inputs_ready: an event after
         which the inputs are complete (a loader's copy-stream event); without it the work is ordered behind the current stream.
-        The inputs must stay unmodified until the consuming forward has run.  Returns None on backends without streams."""
+        The inputs must stay unmodified until the consuming forward has run: an in-place refill of the same buffers (copy_, any
+        in-place op) is detected through the tensors' version counters and the handle is then refused; writes through raw pointers
+        are not seen.  Returns None on backends without streams."""
         dev = xyz1.device
         side = self.side_stream(dev)
         if side is None:
@@ -1301,7 +1334,8 @@ class MoCoPCI(nn.Module):
             # the level-0 self search (0.6 ms with its sorted cloud) on a lane of its own, so that it neither delays the sampling
             # chain nor waits for it
             self_search = self.early_self_search(xyz, laid_out, main)
-        return {"inputs": (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)), "stream": main.stream_id, "xyz": xyz, "laid_out": laid_out,
+        return {"inputs": (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)), "versions": (xyz1._version, xyz2._version),
+                "stream": main.stream_id, "xyz": xyz, "laid_out": laid_out,
                 "pyramid": pyramid, "self_search": self_search, "scope": scope}
 
     def begin(self, xyz1, xyz2, prefetched=None, then_prefetch=None, inputs_ready=None):
@@ -1311,7 +1345,9 @@ class MoCoPCI(nn.Module):
         (Point-Transformer refinement, fusion) and returns out_lst.  A serving loop calls begin(batch k+1) BEFORE finish(batch k):
         the sampling of batch k -- a serial 1.2-1.4 ms chain that leaves 90 % of the chip idle, with nothing of batch k left to
         run beside it -- then overlaps the encoder of batch k+1, and the PointConvD speculation that otherwise fills the wait (4x
-        the work) is not needed.  Same results as forward(); every batch's work is enqueued exactly once.  Arguments as forward()."""
+        the work) is not needed.  Same results as forward(), bit for bit and at every batch size: the deferred tail computes only the
+        sampled rows of PointConvD / the Point-Transformer projection, with the kernels the speculative form runs on every candidate
+        row (lin(like_rows=)); every batch's work is enqueued exactly once.  Arguments as forward()."""
         B = xyz1.shape[0]
         self._check_cache()
         be = ops.backend()
@@ -1373,6 +1409,10 @@ class MoCoPCI(nn.Module):
         main = torch.cuda.current_stream(xyz1.device)
         if h["inputs"] != (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)) or h["stream"] != main.stream_id:
             raise RuntimeError("prefetched handle belongs to other inputs or another stream")
+        if h["versions"] != (xyz1._version, xyz2._version):
+            # a loader refilled the buffers in place (copy_ / in-place ops) after prefetch() laid them out: the handle holds the OLD
+            # contents.  (Writes through raw pointers are invisible to the version counters and remain the caller's responsibility.)
+            raise RuntimeError("the inputs were modified in place after prefetch(): prefetch them again")
         main.wait_event(h["laid_out"])
         return h["xyz"], h["pyramid"], h["self_search"]
 

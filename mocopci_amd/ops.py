@@ -478,8 +478,9 @@ class HipBackend:
             out.append(v)
         return out
 
-    def linear_supported(self, xs, n, few_rows=True):
-        """Whether linear() takes this call.  Beyond what the kernel can do, a shape policy: the fused kernel beats the BLAS
+    def linear_supported(self, xs, n, few_rows=True, policy_rows=None):
+        """Whether linear() takes this call.  policy_rows: decide (and run, see linear()) as for that many rows -- a caller that
+        computes a subset of the rows of a tall product asks for the tall product's kernel, so that both give the same bits.  Beyond what the kernel can do, a shape policy: the fused kernel beats the BLAS
         chain for tall inputs with moderate K (tools/linear_ab.py, MI355X: 1.3-1.9x at rows >= 16384, K <= 320, e.g. 58 -> 31 us
         for 196608 x 32 -> 64 + LeakyReLU) and, since its K loop is staged four chunks per barrier, for the K = 536 -> 64 PointConv
         projections (171 -> 146 us at 196608 rows); it loses for few rows (one 256-row workgroup per 8 waves: 2048-8192 rows do
@@ -491,7 +492,7 @@ class HipBackend:
         if ps is None or len(ps) > 3 or len({p.shape[0] for p in ps}) != 1:
             return False
         k = sum(p.shape[1] for p in ps)
-        rows = ps[0].shape[0]
+        rows = ps[0].shape[0] if policy_rows is None else int(policy_rows)
         if few_rows and self._LIN_FEW_MIN_ROWS <= rows < self._LIN_MIN_ROWS:
             # few rows (the lower pyramid levels): the split-K kernel -- four waves share a 32-row tile and split its K chunks -- beats
             # the library GEMM + activation pair up to 256 output columns (tools/linear_fewrows_ab.py: 33 -> 26 us at 4096 x 1048 ->
@@ -523,8 +524,9 @@ class HipBackend:
         _call("mcp_linear_pack", w, n, len(ks), kk, _lib.fptr(w.contiguous()), None if b is None else _lib.fptr(b.contiguous()), _lib.fptr(packed))
         return packed
 
-    def linear(self, xs, w, b=None, slope=1.0, res=None, packed=None):
-        """act(W [x_0 | x_1 | x_2] + b) [+ res] over the last axis: xs one tensor or up to three pieces of a concatenation (read in
+    def linear(self, xs, w, b=None, slope=1.0, res=None, packed=None, policy_rows=None):
+        """act(W [x_0 | x_1 | x_2] + b) [+ res] over the last axis (policy_rows: the kernel of a product with that many rows, see
+        linear_supported): xs one tensor or up to three pieces of a concatenation (read in
         place, column slices allowed); act(v) = v > 0 ? v : slope v (1.0: none, 0.1: LeakyReLU, 0: ReLU, a PReLU slope).
         One kernel instead of cat + GEMM + activation + add.  Differentiable.  packed: linear_pack(w, b, widths) if kept."""
         def fused(xs_, w_, b_, slope_, res_):
@@ -538,8 +540,8 @@ class HipBackend:
             xp = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
             st = (ctypes.c_int * len(ps))(*[p.stride(0) for p in ps])
             kk = (ctypes.c_int * len(ps))(*ks)
-            _call("mcp_linear", first, rows, n, len(ps), xp, st, kk, float(slope_), _lib.fptr(pk), None if r2 is None else _lib.fptr(r2), n,
-                  _lib.fptr(out), n)
+            _call("mcp_linear_as", first, rows, rows if policy_rows is None else int(policy_rows), n, len(ps), xp, st, kk, float(slope_), _lib.fptr(pk),
+                  None if r2 is None else _lib.fptr(r2), n, _lib.fptr(out), n)
             return out.reshape(*first.shape[:-1], n)
         if isinstance(xs, (tuple, list)) and grad.wants_grad(*xs, w, b, res):
             return grad.linear_twin(xs, w, b, slope, res)  # training: plain autograd over the concatenation

@@ -164,13 +164,13 @@ class OracleBackend:
     def mlp2_pack(self, w1, b1, w2, b2):
         return None
 
-    def linear_supported(self, xs, n, few_rows=True):
+    def linear_supported(self, xs, n, few_rows=True, policy_rows=None):
         return True
 
     def linear_pack(self, w, b, ks):
         return None
 
-    def linear(self, xs, w, b=None, slope=1.0, res=None, packed=None):
+    def linear(self, xs, w, b=None, slope=1.0, res=None, packed=None, policy_rows=None):
         """Conv1d wrapper of the reference (mocopci.py:1111-1127) generalised: Linear over the concatenated pieces, one-slope
         activation, residual."""
         x = torch.cat(list(xs), dim=-1) if isinstance(xs, (tuple, list)) else xs

@@ -182,6 +182,13 @@ def test_prefetched_forwards_are_bit_identical_to_an_isolated_call():
     with pytest.raises(RuntimeError):
         net(y1, y2, prefetched=h)
     torch.cuda.synchronize()
+    # a loader that refills the SAME buffers in place between prefetch() and the forward: the handle holds the old contents
+    z1, z2 = x1.clone(), x2.clone()
+    h = net.prefetch(z1, z2)
+    z1.copy_(y1)
+    with pytest.raises(RuntimeError):
+        net(z1, z2, prefetched=h)
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("tail_on_own_stream", [False, True])
@@ -213,3 +220,27 @@ def test_two_batches_in_flight_give_the_isolated_results(tail_on_own_stream):
     assert len(outs) == len(order)
     for k, (o, which) in enumerate(zip(outs, order)):
         assert all(torch.equal(a, b) for a, b in zip(o, want[which])), f"pipelined batch {k} differs from its isolated forward"
+
+
+@pytest.mark.parametrize("b", [1, 2])
+def test_pipelined_forms_match_the_isolated_forward_at_small_batches(b):
+    """below 3 sequences the sampled rows of the two PointConvD stages number fewer than 16384, where a Linear on them
+    alone would take the few-row split-K kernel (another K summation order) while an isolated forward() computes every candidate
+    row with the full-K kernel and gathers.  The prefetched / begin() + finish() forms ask for the tall product's kernels
+    (MoCoPCI.lin(like_rows=), mcp_linear_as), so all three forms return the same bits at every batch size."""
+    from mocopci_amd import synth
+    from tests import harness_checks as hc
+    net = hc.build_model(DEV)
+    x1, x2, _ = synth.make_batch(2, b, 8192, device=DEV)
+    want = net(x1, x2)
+    torch.cuda.synchronize()
+    h = net.prefetch(x1, x2)
+    got = net(x1, x2, prefetched=h)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(got, want)), "prefetched forward differs from the isolated one"
+    pend = net.begin(x1, x2)
+    other = net.begin(x1, x2)
+    outs = [net.finish(pend), net.finish(other)]
+    torch.cuda.synchronize()
+    for o in outs:
+        assert all(torch.equal(p, q) for p, q in zip(o, want)), "begin() / finish() differs from the isolated forward"

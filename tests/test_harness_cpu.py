@@ -145,6 +145,18 @@ def test_forward_on_scan_weights_matches_reference_and_stays_on_the_scan(oracle_
     assert float(g["chamfer"].max()) < 15.0
 
 
+def test_forward_on_scan_weights_at_the_baseline_point_count(oracle_backend):
+    """The same at BASELINE's point count: sequence 0 of config 2, N = 8192 -- the cloud bench.py's `quality` object runs -- against
+    the REFERENCE'S stored forward under the on-scan weights (tests/golden/forward_scan_n8192.npz): the oracle backend reproduces
+    the reference's Chamfer-vs-GT (4.0, a quality number).  Measured: 1.03e-5 / 3e-6 / 9e-6 relative on the three frames -- the
+    residue is near-tie neighbour flips between torch-CPU's dense layers here and in the reference run, and it sits AT the 1e-5 of
+    north_star, so this CPU check of the oracle allows 2e-5; the HIP path is held to 1e-5 (tests/test_model_gpu.py)."""
+    import numpy as np, os
+    hc.run_forward_check("cpu", "forward_scan_n8192", 2, 1, 8192, orc.chamfer, weights="scan", chamfer_rtol=2e-5)
+    g = np.load(os.path.join(hc.GOLD, "forward_scan_n8192.npz"))
+    assert float(g["chamfer"].max()) < 5.0
+
+
 def test_quality_metric_reacts_to_a_wrong_neighbour_search(oracle_backend):
     """Under the on-scan weights Chamfer-vs-GT is a quality number: a kernel bug that hits 2 % of the points -- every 50th
     32-neighbour list keeps its 16 nearest but takes its far half from a point half a cloud away -- moves it by more than 10 %
@@ -188,3 +200,19 @@ def test_serving_loop_api_without_streams(oracle_backend):
     got = net.finish(pending)
     assert all(torch.equal(a, b) for a, b in zip(got, want))
     assert all(torch.equal(a, b) for a, b in zip(net(x1, x2, prefetched=None, then_prefetch=(x1, x2)), want))
+
+
+def test_inference_cache_epoch_is_per_model():
+    """a tensor assigned on ONE model (or constructing another model) must not invalidate the cache key of the others,
+    and an assignment on the root module itself must be seen."""
+    from mocopci_amd.model import MoCoPCI
+    a = hc.build_model("cpu")
+    va = a._state_version()
+    b = MoCoPCI()                                                     # constructing a second model registers ~500 tensors
+    b.encoder.level0_lift.composed_module._modules["0"].weight = torch.nn.Parameter(torch.zeros_like(b.encoder.level0_lift.composed_module._modules["0"].weight))
+    assert a._state_version() == va                                   # ... none of which belong to a
+    vb = b._state_version()
+    b.some_root_tensor = torch.zeros(1)                               # root-level assignment
+    assert b._state_version() != vb
+    a.encoder.level0_lift.composed_module._modules["0"].weight = torch.nn.Parameter(torch.ones_like(a.encoder.level0_lift.composed_module._modules["0"].weight))
+    assert a._state_version() != va

@@ -3,6 +3,8 @@ to the compiler's hazard recogniser and wait-count pass, so the few raw instruct
 instruction stream; packed-fp32 instructions must not appear at all."""
 import glob
 import os
+
+import pytest
 import subprocess
 import sys
 
@@ -46,6 +48,9 @@ def test_lint_flags_the_hazards_it_is_there_for(tmp_path):
 
 
 def test_shipped_device_code_passes_the_lint():
+    import shutil
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc: the device assembly cannot be generated on this machine")
     isa = os.path.join(ROOT, "mocopci_amd", "csrc", "isa")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "mocopci_amd", "csrc"), "-j4", "-s", "isa"])
     files = sorted(glob.glob(os.path.join(isa, "*.s")))

@@ -33,6 +33,13 @@ def test_forward_on_scan_weights_matches_reference_on_gpu():
     hc.run_forward_check("cuda:0", "forward_scan_n2048", 8, 1, 2048, ops.backend().chamfer, weights="scan")
 
 
+def test_forward_on_scan_weights_at_the_baseline_point_count_on_gpu():
+    """north_star: "Chamfer ... within 1e-5 relative", at the benchmark's point count and on a cloud where the metric can see a wrong
+    kernel: sequence 0 of config 2, N = 8192, on-scan weights -- HIP path against the REFERENCE'S stored forward
+    (tests/golden/forward_scan_n8192.npz; Chamfer-vs-GT 4.0 against E|gt|^2 = 1067 under the stress weights)."""
+    hc.run_forward_check("cuda:0", "forward_scan_n8192", 2, 1, 8192, ops.backend().chamfer, weights="scan")
+
+
 def test_forward_full_size_runs_and_is_deterministic():
     # config 2 shape at B=2 (N=8192): two runs give identical output (no atomics on the forward path)
     from mocopci_amd import synth
