@@ -39,12 +39,22 @@ SPLIT_PRODUCTS = 6              # bf16 partial products per fp32 product on the 
 # profiles/r02_mfma_sustained.txt: power management holds the clock near 1.8 GHz; 0.99 of the datasheet figure with all-ones operands).
 # Reported beside `peak`, never instead of it.
 MFMA_BF16_SUSTAINED_TFLOPS = 1865.0
-NPOINTS = 8192
+NPOINTS = 8192     # the default workload (--config c2); main() rebinds both for --config c4
 B_PER_GPU = 8
+HBM_COPY_PEAK_GBS = 6290.0      # measured float4 copy (MI355X_MICROARCH.md; SURVEY 8(d) prices the point-set path against it)
+# --config: which BASELINE.json configuration the run measures.  c2 (default) is the one the metric is quoted on (configs[1]; configs[2]
+# is the same per-GPU workload on 8 GPUs); c4 / c5 are the "stress" and "roofline" configurations (configs[3], configs[4]).
+CONFIGS = {
+    "c2": dict(config_id=2, npoints=8192, batch=8, kw={}, golden="forward_c2_n8192",
+               workload="KITTI-o-like NL-Drive synthetic, N=8192, batch=8 per GPU, 3 interp frames (BASELINE configs[1]; configs[2] at 8 GPUs)"),
+    "c4": dict(config_id=4, npoints=16384, batch=8, kw=dict(extent=50.0, zlo=-5.0, zhi=3.0), golden=None,
+               workload="NuScenes-like NL-Drive synthetic, N=16384 (x,y in +-50, z in [-5,3]), batch=8, 3 interp frames (BASELINE configs[3]: LDS-tile / "
+                        "ball-query radius stress) + the standalone ball_query (M=2048, r in {0.5,1,2,4}) and three_nn launches of SURVEY 8(d)"),
+}
 FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock", "mlp", "linear")
 HEADLINE = "fusion"  # the single kernel symbol with the most time on a step's critical (main) stream
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
-PMC_STAMP = os.path.join(ROOT, "profiles", "r03_pmc_sources.json")  # sha256 of every csrc file the profiled library was built from
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
+PMC_STAMP = os.path.join(ROOT, "profiles", "r04_pmc_sources.json")  # sha256 of every csrc file the profiled library was built from
 
 NAMES = {
     "fps": "fps_spatial_kernel / fps_resident_kernel (mcp_furthest_point_sampling_ws)",
@@ -127,6 +137,47 @@ def algorithmic_work(kernel, calls):
     raise KeyError(kernel)
 
 
+def compulsory_bytes(kernel, calls):
+    """SURVEY.md 8(d) COMPULSORY bytes of the point-set families (inputs read once + outputs written once), for the end-to-end line."""
+    if kernel == "fps":
+        return sum(b * (12 * n + 4 * m) for (b, n, m) in calls)
+    if kernel == "knn":
+        return sum(b * (12 * q + 12 * n + 4 * q * k) for (b, q, n, k) in calls)
+    if kernel == "knn_cosine":
+        return sum(b * (4 * c * (q + n) + 4 * q * 16) for (b, q, n, c) in calls)
+    if kernel == "cross":   # 4B(2C N1 + C N2 + 3(N1+N2) + K N1), N2 = N1 at every call of this graph
+        return sum(4 * b * (2 * d * n1 + d * n1 + 3 * 2 * n1 + 32 * n1) for (b, n1, d) in calls)
+    if kernel == "pointconv":   # group(C=D+3,S,K=32): B(4SK + 8CSK) is the REFERENCE's materialised group; compulsory: neighbour lists + features read once + output
+        return sum(b * s * (4 * 32 + 4 * (d + 3) + 4 * d) for (b, s, d) in calls)
+    if kernel == "fusion":      # two clouds + 64 neighbour indices in, one cloud out
+        return sum(b * n * (12 + 12 + 4 * 64 + 12) for (b, n) in calls)
+    if kernel == "ptblock":     # xyz + q,k,v rows + 16 neighbour indices in, 64 channels out
+        return sum(b * n * (12 + 3 * 256 + 4 * 16 + 256) for (b, n) in calls)
+    raise KeyError(kernel)
+
+
+POINTSET_FAMILIES = ("fps", "knn", "knn_cosine", "cross", "pointconv", "fusion", "ptblock")
+
+
+def pointset_end_to_end(timed, calls, steps):
+    """SURVEY 8(d)'s end-to-end line: (sum of compulsory bytes of all point-set kernels per forward) / (time in those kernels),
+    against the measured HBM copy peak.  It prices the whole point-set path as if it were a streaming pass; it is far below the peak
+    because none of these kernels is HBM-bound once the N x N matrices are gone (their own bounds are in the per-family entries)."""
+    total_b, total_ms, per = 0.0, 0.0, {}
+    for k in POINTSET_FAMILIES:
+        launches, kms = timed.get(k, (0, 0.0))
+        if not launches:
+            continue
+        b = compulsory_bytes(k, calls[k])
+        per[k] = {"compulsory_MB_per_step": b / 1e6, "kernel_ms_per_step": kms / steps}
+        total_b += b
+        total_ms += kms / steps
+    ach = total_b / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+    return {"what": "sum of SURVEY 8(d) compulsory bytes of the point-set kernel families per step / time in those kernels (instrumented pass)",
+            "compulsory_MB_per_step": total_b / 1e6, "kernel_ms_per_step": total_ms, "achieved_GBs": ach, "peak_GBs": HBM_COPY_PEAK_GBS,
+            "frac_of_measured_copy_peak": ach / HBM_COPY_PEAK_GBS, "frac_of_spec_peak": ach / HBM_PEAK_GBS, "families": per}
+
+
 def log_call_shapes(be, step):
     """One untimed step with shape-recording wrappers on the backend's entry points.  Exactly one record per timed launch: the
     3-NN searches inside interp3 / interp3_search reach the timer through be.knn, so only be.knn records them; the fused
@@ -196,7 +247,7 @@ def roofline_entries(timed, calls, steps, pmc):
         p = pmc.get(kname, {})
         if "hbm_bytes_per_launch" in p:
             e["traffic"] = p["hbm_bytes_per_launch"]
-            e["traffic_source"] = "profiles/r03_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build, read side doubled per the gfx950 rule)"
+            e["traffic_source"] = "profiles/r04_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build, read side doubled per the gfx950 rule)"
             e["traffic_stale"] = PMC_IS_STALE
         for key in ("valu_busy_frac_of_chip", "mfma_busy_frac_of_chip", "mean_resident_waves_per_simd"):
             if key in p:
@@ -261,6 +312,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=("c2", "c4", "c5"), default="c2",
+                    help="BASELINE.json configuration: c2 = configs[1]/[2] (N=8192, B=8 per GPU: the one the metric is quoted on, default); "
+                         "c4 = configs[3] (N=16384, B=8, model forward + ball_query / three_nn launches); c5 = configs[4] (N=65536, B=8: "
+                         "FPS 65536->2048 + 32-NN with Q=2048 and Q=N, kernels only -- the model is not run at this size, SURVEY 8(d))")
     ap.add_argument("--serial", action="store_true", help="do not pipeline the input-only sampling pyramid across consecutive steps")
     ap.add_argument("--pipeline", choices=("two-batch", "prefetch", "event"), default="two-batch",
                     help="two-batch: prefetch + the tail of batch k-1 (after its refinement-stage sampling) is enqueued behind the first part of "
@@ -270,6 +325,13 @@ def main():
                                                             "hardware queues, not reproducibly; more hardware queues make it worse)")
     args = ap.parse_args()
 
+    global NPOINTS, B_PER_GPU
+    if args.config == "c5":
+        if args.gpus != 1:
+            raise SystemExit("--config c5 is a single-GPU kernel run")
+        return run_c5(args)
+    cfg = CONFIGS[args.config]
+    NPOINTS, B_PER_GPU = cfg["npoints"], cfg["batch"]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Invoked plainly (`python bench.py --gpus N`): fan out to one fresh rank process per GPU, as the reference's only
         # multi-GPU mechanism does with threads (nn.DataParallel, train.py:73-80).  This process has not touched the GPU
@@ -296,7 +358,7 @@ def main():
     net.load_state_dict(synth.weights_by_name(net._spec), strict=True)
     net = net.to(dev)
     # config 2 (N=8192, B=8 per GPU); rank r holds sequences [8r, 8r+8) of the global batch
-    x1, x2, gt = synth.make_batch(2, B_PER_GPU, NPOINTS, device=dev, first_sample=rank * B_PER_GPU)
+    x1, x2, gt = synth.make_batch(cfg["config_id"], B_PER_GPU, NPOINTS, device=dev, first_sample=rank * B_PER_GPU, **cfg["kw"])
 
     # The inputs are resident and complete: an event recorded here lets the input-only sampling pyramid of step k+1 be issued
     # behind it instead of behind step k's tail (MoCoPCI.forward(inputs_ready=...): pipelining of consecutive batches, as a
@@ -402,9 +464,12 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        # fp32 values end to end; where a fused MLP layer runs on the matrix pipe, each fp32 product is the sum of six bf16 x bf16 partial
+        # products of an exact 3-way operand split (fp32 accumulation): fp32-class accuracy (~4 ulp from the f32-input MFMA build), and
+        # the neighbour-index paths (FPS, KNN, cosine KNN) stay on exact f32 arithmetic
+        "dtype": "f32 (fused MLP layers: fp32 products as 6 bf16-MFMA partials of an exact 3-way split, fp32 accumulate; index paths exact f32)",
         "data": "synthetic",
-        "config": {"workload": "KITTI-o-like NL-Drive synthetic, N=8192, batch=8 per GPU, 3 interp frames (BASELINE configs[1]; configs[2] at 8 GPUs)",
+        "config": {"workload": cfg["workload"], "bench_config": args.config,
                    "npoints": NPOINTS, "batch_per_gpu": B_PER_GPU, "global_batch": B_PER_GPU * world,
                    "parallelism": f"sequence-sharded x{world}, final all_gather over RCCL" if world > 1 else "single GPU",
                    "weights": "deterministic by-name synthetic, eval mode",
@@ -428,9 +493,9 @@ def main():
         "chamfer_vs_gt_untrained_weights": chamfer,
         "emd_vs_gt_untrained_weights": emd,
     }
-    if rank == 0:
+    if rank == 0 and args.config == "c2":
         result["quality"] = quality_on_scan_weights(dev)
-    par = parity_vs_reference(local, rank)
+    par = parity_vs_reference(local, rank) if cfg["golden"] else None
     if par is not None:
         result["parity"] = par
 
@@ -450,9 +515,12 @@ def main():
         live["alone"] = {k: alone[k] for k in ("achieved", "frac", "avg_launch_us", "kernel_ms_per_step", "timed_in")}
         result["roofline"] = live
         result["roofline_others"] = sorted((e for e in entries if e is not alone), key=lambda e: -e["kernel_ms_per_step"])
+    result["pointset_end_to_end"] = pointset_end_to_end(timed, calls, inst_steps)
+    if args.config == "c4" and rank == 0:
+        result["roofline_others"] = result.get("roofline_others", []) + c4_pointnet2_launches(x1, dev)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
+        result["cpu_baseline"] = cpu_baseline(cfg, batch=B_PER_GPU if args.config == "c2" else 2)
 
     if rank == 0:
         print(json.dumps(result))
@@ -473,8 +541,9 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(batch=B_PER_GPU):
-    """The same graph on host cores: oracle backend ("port"), one full batch of the same workload (about 10-20 s)."""
+def cpu_baseline(cfg, batch):
+    """The same graph on host cores: oracle backend ("port"), a bounded sample of the same workload (about 10-20 s): the full batch of
+    config 2, two sequences of config 4."""
     from mocopci_amd import ops, synth
     from mocopci_amd.model import MoCoPCI
     from oracle.backend import OracleBackend
@@ -484,7 +553,8 @@ def cpu_baseline(batch=B_PER_GPU):
     torch.set_num_threads(cores)
     net = MoCoPCI()
     net.load_state_dict(synth.weights_by_name(net._spec), strict=True)
-    x1, x2, _ = synth.make_batch(2, batch, NPOINTS)
+    n = cfg["npoints"]
+    x1, x2, _ = synth.make_batch(cfg["config_id"], batch, n, **cfg["kw"])
     from oracle import pointset as orc
     orc.lib().orc_set_threads(cores)
     prev = ops.set_backend(OracleBackend())
@@ -495,8 +565,131 @@ def cpu_baseline(batch=B_PER_GPU):
     finally:
         ops.set_backend(prev)
     return {"value": 3.0 * batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"one step of the same workload ({batch} sequences, N={NPOINTS}, {3 * batch} frames), {dt:.1f} s; "
+            "sample": f"one forward of the same workload over {batch} sequences (N={n}, {3 * batch} frames), {dt:.1f} s; "
                       "C oracle point-set ops (OpenMP) + torch-CPU dense ops"}
+
+
+def _event_time(fn, reps):
+    """Average duration of fn() in seconds, HIP events on the stream the launches go to (torch's current stream)."""
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / reps
+
+
+def c4_pointnet2_launches(x1, dev, reps=20):
+    """the standalone pointnet2 launches of the legacy PointNet++ layers (models/models.py:18-22) on the
+    N=16384 clouds of this run -- ball_query at M=2048 centres, r in {0.5, 1, 2, 4}, nsample in {16, 16, 8, 8}, and three_nn
+    (16384 unknown, 2048 known) -- through the reference-API functions (mocopci_amd.pointnet2_utils -> the C ABI), each with its
+    compulsory bytes over its launch duration."""
+    from mocopci_amd import pointnet2_utils as pu
+    xyz = x1.transpose(1, 2).contiguous()                    # (B,16384,3)
+    B, N, _ = xyz.shape
+    centres = xyz[:, :2048].contiguous()
+    out = []
+    for r, ns in ((0.5, 16), (1.0, 16), (2.0, 8), (4.0, 8)):
+        sec = _event_time(lambda: pu.ball_query(r, ns, xyz, centres), reps)
+        byt = B * (12 * 2048 + 12 * N + 4 * 2048 * ns)
+        out.append({"kernel": f"ball_query_kernel (mcp_ball_query) r={r} nsample={ns}, M=2048, N={N}", "bound": "hbm", "achieved": byt / sec / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "launches": reps,
+                    "avg_launch_us": sec * 1e6, "note": "compulsory bytes B*(12M+12N+4*M*nsample) (SURVEY 8d) / launch duration; the kernel scans "
+                    "LDS tiles of the cloud per query wave with early exit at nsample hits, so small radii scan most of the cloud: VALU-bound, not HBM-bound"})
+    sec = _event_time(lambda: pu.three_nn(xyz, centres), reps)
+    byt = B * (12 * N + 12 * 2048 + 24 * N)
+    out.append({"kernel": f"three_nn_kernel (mcp_three_nn) n={N} unknown, m=2048 known", "bound": "hbm", "achieved": byt / sec / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": byt / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "launches": reps, "avg_launch_us": sec * 1e6,
+                "note": "compulsory bytes B*(12n+12m+24n) (SURVEY 8d) / launch duration; n*m = 33.5 M distance evaluations per cloud: VALU-bound"})
+    return out
+
+
+def run_c5(args):
+    """BASELINE configs[4]: synthetic N=65536 dense scan, batch 8 -- the FPS + KNN kernels only (the reference formulation
+    cannot hold a 16 GiB-per-element distance matrix, so the model is not run at this size).  A step = FPS 65536 -> 2048 of the
+    eight clouds, the 32-NN of the 2048 sampled points in their cloud, and the 32-NN self search (Q = N = 65536)."""
+    from mocopci_amd import ops
+    from tests.golden_inputs import big_cloud      # the seeded cloud of the full-shape parity test (tests/test_ops_gpu.py:test_config5_full_shape_pins)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    be = ops.backend()
+    B, N, M, K = 8, 65536, 2048, 32
+    x = big_cloud(N, seed=5, batch=B).to(dev)
+    state = {}
+
+    def step():
+        sel, pts = be.fps(x, M, with_points=True)
+        with be.cloud_scope():           # one sorted form of the cloud serves both searches, as inside a forward
+            state["knn_q"] = be.knn(pts, x, K)
+            state["knn_n"] = be.knn(x, x, K)
+        state["sel"] = sel
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # per-kernel durations, HIP events on the launch stream, same calls
+    pts = be.group_rows(x, state["sel"])
+    t_fps = _event_time(lambda: be.fps(x, M), 5)
+    with be.cloud_scope():
+        be.knn(x, x, K)                 # builds the sorted cloud inside the scope: the timed launches below are the searches alone
+        t_build = _event_time(lambda: be._build_cloud(x), 5)
+        t_kq = _event_time(lambda: be.knn(pts, x, K), 5)
+        t_kn = _event_time(lambda: be.knn(x, x, K), 5)
+
+    def entry(kernel, sec, byt, note, **extra):
+        e = {"kernel": kernel, "bound": "hbm", "achieved": byt / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / sec / 1e9 / HBM_PEAK_GBS,
+             "traffic": None, "launches": 5, "avg_launch_us": sec * 1e6, "note": note}
+        e.update(extra)
+        return e
+    fps_stream = B * (M - 1) * 20 * N
+    fps = entry("fps_tiled_kernel (mcp_furthest_point_sampling_fresh, caller workspace)", t_fps, fps_stream,
+                "achieved = bytes of the REFERENCE'S streaming formulation B*(M-1)*20*N (SURVEY 8d: 21.5 GB) over the launch -- not a utilisation: "
+                "the kernel keeps tile boxes in registers and touches only the tiles a new centre can affect",
+                compulsory_GBs=B * (12 * N + 4 * M) / t_fps / 1e9, us_per_iteration=1e6 * t_fps / (M - 1))
+    kq = entry("knn_walk_kernel K=32, Q=2048 sampled points, N=65536 (mcp_knn_pruned)", t_kq, B * (12 * M + 12 * N + 4 * M * K),
+               "compulsory bytes B*(12Q+12N+4QK); reference formulation 24*B*Q*N = %.1f GB" % (24.0 * B * M * N / 1e9),
+               reference_formulation_GBs=24.0 * B * M * N / t_kq / 1e9)
+    kn = entry("knn_walk_kernel K=32, Q=N=65536 self search (mcp_knn_pruned)", t_kn, B * (12 * N + 12 * N + 4 * N * K),
+               "compulsory bytes B*(12Q+12N+4QK); reference formulation 24*B*Q*N = %.0f GB (a 16 GiB distance matrix per cloud)" % (24.0 * B * N * N / 1e9),
+               reference_formulation_GBs=24.0 * B * N * N / t_kn / 1e9)
+    bc = entry("mcp_morton_codes + sort + mcp_tile_boxes (sorted form of the 65536-point clouds)", t_build, B * (12 * N * 2 + 4 * N),
+               "bytes: cloud read, sorted cloud + permutation written; torch.sort of the Morton codes in between (N > 16384: outside the fused builder)")
+    result = {"metric": "clouds/sec through FPS 65536->2048 + 32-NN (Q=2048 and Q=N) [BASELINE configs[4]: kernels only]", "value": B * args.steps / elapsed,
+              "unit": "clouds/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "synthetic N=65536 dense scan (x,y in +-40, z in +-3, 5 % duplicated points), batch=8, 1xMI355X: FPS 65536->2048 + "
+                                     "32-NN Q=2048 + 32-NN Q=N per step (BASELINE configs[4])", "bench_config": "c5", "npoints": N, "batch_per_gpu": B},
+              "roofline": kn, "roofline_others": [fps, kq, bc]}
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_c5(x.cpu(), M, K)
+    print(json.dumps(result))
+
+
+def cpu_baseline_c5(x, M, K):
+    """The oracle (C, OpenMP) on a bounded sample: FPS 65536 -> 2048 of ONE cloud, the Q=2048 search of one cloud, a 2048-query slice of
+    the Q=N search; scaled to clouds/s of the same step."""
+    from oracle import pointset as orc
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    orc.lib().orc_set_threads(cores)
+    one = x[:1].contiguous()
+    t0 = time.perf_counter()
+    sel = orc.furthest_point_sample(one, M)
+    t_fps = time.perf_counter() - t0
+    pts = torch.gather(one, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    t0 = time.perf_counter()
+    orc.knn(pts, one, K)
+    t_q = time.perf_counter() - t0
+    per_cloud = t_fps + t_q + t_q * (one.shape[1] / M)        # the Q=N search = 32 slices of 2048 queries at the slice's rate
+    return {"value": 1.0 / per_cloud, "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": f"one cloud: oracle FPS 65536->2048 ({t_fps:.1f} s) + exhaustive 32-NN of 2048 queries ({t_q:.1f} s); the Q=N search priced as "
+                      f"32 such slices ({t_q * one.shape[1] / M:.0f} s, not run in full)"}
 
 
 if __name__ == "__main__":
