@@ -314,7 +314,7 @@ int launch_wide(int bf, int nq, int nk, int heads, const float *q, int qs, const
     auto kern = attention_wide_kernel<HD>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(nq, 32 * WAVES), heads, bf), dim3(64 * WAVES), WideCfg<HD>::LDS_BYTES, s, nq, nk, q, qs, k, ks, v,

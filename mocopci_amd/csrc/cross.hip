@@ -316,7 +316,7 @@ int launch_cross(long long total, int n1, int n2, const float *xyz1, const float
     auto kern = cross_kernel<D, SPLIT>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     // at least 8 points per wave so the weight staging is amortised

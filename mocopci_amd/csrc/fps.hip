@@ -713,7 +713,7 @@ int launch_tiled(int b, int n, int m, const float *xyz, float *temp, int *idx, f
     float *st = reinterpret_cast<float *>(ws + (size_t)b * np * sizeof(float4));
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     hipLaunchKernelGGL(fps_tiled_kernel, dim3(b), dim3(TL_T), lds, s, n, m, tiles, lds_idx, xyz, temp, idx, pts, sx, st);
@@ -737,7 +737,7 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
         auto kern = fps_resident_kernel<T, P, J, GENERIC, true>;
         static McpPerDeviceOnce attr_once;
         if (attr_once.need()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
             attr_once.done();
         }
         hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + xyz_bytes + idx_bytes, s, n, m, L, xyz, temp, idx, pts);
@@ -746,7 +746,7 @@ int launch_resident(int b, int n, int m, int L, const float *xyz, float *temp, i
         auto kern = fps_resident_kernel<T, P, J, GENERIC, false>;
         static McpPerDeviceOnce attr_once2;
         if (attr_once2.need()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
             attr_once2.done();
         }
         hipLaunchKernelGGL(kern, dim3(b), dim3(T), slot_bytes + idx_bytes, s, n, m, L, xyz, temp, idx, pts);
@@ -766,10 +766,10 @@ int launch_spatial(int b, int n, int m, int L, const float *xyz, float *temp, in
     }
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_spatial_kernel<T, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     (void)L;  // n >= 1024: the reference block size is 1024 (asserted by the caller)

@@ -310,7 +310,7 @@ MCP_EXPORT int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2
 #endif
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fusion_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(fusion_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     hipLaunchKernelGGL(fusion_split_kernel, dim3(grid), dim3(64 * WAVES), SP_LDS_BYTES, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, out);

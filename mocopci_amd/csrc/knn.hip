@@ -298,7 +298,7 @@ int launch_queue(int b, int q, int n, int k, const float *query, const float *re
     auto kern = knn_queue_kernel<K, MODE, SPLIT>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 64), b), dim3(64 * SPLIT), lds, s, q, n, k, query, ref, idx, dist);

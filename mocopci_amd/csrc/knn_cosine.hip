@@ -179,7 +179,7 @@ int launch_cosine(int b, int q, int n, int k, const float *nq, const float *nr, 
     auto kern = knn_cosine_kernel<C>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 32 * WAVES), b), dim3(64 * WAVES), lds, s, q, n, k, nq, nr, idx, dist);

@@ -219,7 +219,7 @@ int launch_build_cloud(int b, int n, int tiles, const float *xyz, float *sorted_
     const size_t lds = 512 + sizeof(typename CloudSort<IPT>::Lds);
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(b), dim3(BT), lds, s, n, tiles, xyz, sorted_xyz, perm, boxes);
@@ -1154,7 +1154,7 @@ int launch_pruned_tpl(int b, int q, int n, int tiles, int k, const float *query,
     auto kern = knn_pruned_kernel<K, MODE, SUB, TPL>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {  // lets the CU's whole 160 KB LDS count towards residency (default budget: 64 KB)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 64 / SUB), b), dim3(64), lds, s, q, n, tiles, k, query, qperm,

@@ -397,7 +397,7 @@ int launch_linear_kc(long long rows, int n, const Segs &sg, int nseg, int total_
     static_assert((2 * stage_floats(NT, KC, NW) + (size_t)NW * XT) * sizeof(float) <= 160 * 1024, "LDS budget");
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     const long long groups = (rows + 32LL * NW - 1) / (32LL * NW);

@@ -165,7 +165,7 @@ int launch_mlp2(long long rows, int hidden, int cout, float slope, const float *
     const size_t lds = 2 * (size_t)((chunk_floats(CIN, COT) / 4 + 64 * NW - 1) / (64 * NW)) * (64 * NW) * 4 * sizeof(float);
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
         attr_once.done();
     }
     const long long groups = (rows + 32LL * NW - 1) / (32LL * NW);

@@ -496,7 +496,7 @@ MCP_EXPORT int mcp_pointconv_linear(int b, int n, int s, int d, int k, const flo
         auto kern = pointconv_linear_kernel<32, 1>;
         static McpPerDeviceOnce attr_once;
         if (attr_once.need()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
             attr_once.done();
         }
         constexpr int lds = FusedCfg<32, 1>::LDS_BYTES;
@@ -506,7 +506,7 @@ MCP_EXPORT int mcp_pointconv_linear(int b, int n, int s, int d, int k, const flo
         auto kern = pointconv_linear_kernel<64, 2>;
         static McpPerDeviceOnce attr_once;
         if (attr_once.need()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
             attr_once.done();
         }
         constexpr int lds = FusedCfg<64, 2>::LDS_BYTES;

@@ -91,7 +91,9 @@ def main():
             # kernel duration in shader cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs, so /8 is the busy-cycle count at the
             # clock the kernel actually ran at (MFMA-heavy kernels run near 2.0 GHz, not the nominal 2.4); nominal otherwise
             cycles = c["GRBM_GUI_ACTIVE"] / 8.0 if "GRBM_GUI_ACTIVE" in c else e["avg_dispatch_us_under_pmc"] * 1e3 * CLOCK_GHZ
-            if "GRBM_GUI_ACTIVE" in c:
+            # GRBM_GUI_ACTIVE / 8 / wall time reads high on short dispatches (MI355X_MICROARCH.md, DVFS give-back: the quotient is
+            # only meaningful from about 0.3 ms up -- round 3 published 5.4-5.9 "GHz" for 5 us kernels): not reported below that
+            if "GRBM_GUI_ACTIVE" in c and e["avg_dispatch_us_under_pmc"] >= 300.0:
                 e["effective_clock_ghz"] = cycles / (e["avg_dispatch_us_under_pmc"] * 1e3)
             e["mean_resident_waves_per_simd"] = 4.0 * wave / (cycles * N_SIMD)
             if "SQ_ACTIVE_INST_VALU" in c:
