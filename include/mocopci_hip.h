@@ -94,6 +94,15 @@ int mcp_group_points_grad(int b, int c, int n, int npoints, int nsample, const f
 int mcp_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
                    mcp_stream_t stream);
 
+/* QueryAndGroup.forward as one launch                         pointnet2/pointnet2_utils.py:231-264
+ * (= ball_query_wrapper + a transposed copy of xyz + 2 x group_points_wrapper + subtraction + cat in the reference).
+ * xyz (B,N,3), new_xyz (B,M,3) centres, features (B,C,N) or NULL -> out (B, CT, M, nsample), CT = (use_xyz or no features ? 3 : 0) +
+ * (features ? C : 0): channels 0..2 = neighbour coordinates relative to the centre, then the grouped feature channels; neighbours =
+ * the first nsample points within `radius` in index order, padded with the first hit; a centre with no hit groups point 0
+ * (the reference's pre-zeroed idx).  nsample <= 64 (MCP_ERR_UNSUPPORTED above); features NULL needs use_xyz. */
+int mcp_query_and_group(int b, int n, int m, int c, float radius, int nsample, int use_xyz, const float *xyz, const float *new_xyz,
+                        const float *features, float *out, mcp_stream_t stream);
+
 /* three_nn_wrapper(b,n,m,unknown,known,dist2,idx)            interpolate.cpp:14-24, interpolate_gpu.cu:9-74
  * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) SQUARED distances, idx (B,n,3). */
 int mcp_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, mcp_stream_t stream);

@@ -183,6 +183,58 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_kernel(int n, int m,
         for (int l = min(cnt, nsample) + lane; l < nsample; l += 64) o[l] = first;
 }
 
+// QueryAndGroup.forward (pointnet2/pointnet2_utils.py:231-264) as ONE launch: the reference runs ball_query, transposes the cloud,
+// groups it, subtracts the centres, groups the features and concatenates -- three kernels, two transposed copies, a cat.  Here a
+// wave owns a centre: the ball query above leaves its nsample hits in an LDS row, then lane (channel offset, slot) gathers
+// 64 / nsample output channels per pass -- relative coordinates first (xyz is read in its (B,N,3) layout: no transposed copy),
+// then the (B,C,N) feature rows -- and writes the (B, 3+C, M, nsample) layout directly.  nsample <= 64.
+__global__ __launch_bounds__(64 * BQ_WAVES) void query_and_group_kernel(int n, int m, int c, float radius2, int nsample, int xyz_ch,
+                                                                        const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                        const float *__restrict__ features, float *__restrict__ out) {
+    __shared__ int s_idx[BQ_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * BQ_WAVES + wave;
+    if (p >= m) return;  // whole wave; no workgroup barriers below
+    const float *q = new_xyz + ((size_t)b * m + p) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float *rb = xyz + (size_t)b * n * 3;
+    s_idx[wave][lane] = 0;  // a centre with no hit groups point 0 (the reference's pre-zeroed idx, pointnet2_utils.py:218)
+    __builtin_amdgcn_wave_barrier();
+    int cnt = 0, first = -1;
+    for (int base = 0; base < n && cnt < nsample; base += 64) {
+        const int k = base + lane;
+        bool hit = false;
+        if (k < n) hit = mcp_sqdist3(qx, qy, qz, rb[(size_t)k * 3 + 0], rb[(size_t)k * 3 + 1], rb[(size_t)k * 3 + 2]) < radius2;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        if (mask) {
+            if (first < 0) first = base + (int)__builtin_ctzll(mask);
+            const int rank = cnt + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (hit && rank < nsample) s_idx[wave][rank] = k;
+            cnt += (int)__builtin_popcountll(mask);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (first >= 0 && lane >= min(cnt, nsample) && lane < nsample) s_idx[wave][lane] = first;
+    __builtin_amdgcn_wave_barrier();
+    const int cpl = 64 / nsample;                 // output channels per pass
+    const int slot = lane % nsample, coff = lane / nsample;
+    const int ct = xyz_ch + (features ? c : 0);   // output channels
+    const int id = s_idx[wave][slot];
+    const float centre[3] = {qx, qy, qz};
+    if (coff < cpl) {
+        for (int ch = coff; ch < ct; ch += cpl) {
+            float v;
+            if (ch < xyz_ch) {
+                v = rb[(size_t)id * 3 + ch] - (ch == 0 ? centre[0] : ch == 1 ? centre[1] : centre[2]);
+            } else {
+                v = features[((size_t)b * c + (ch - xyz_ch)) * n + id];
+            }
+            out[(((size_t)b * ct + ch) * m + p) * nsample + slot] = v;
+        }
+    }
+}
+
 // K7  interpolate_gpu.cu:9-52.  Lane per unknown point; known points through an LDS tile.
 constexpr int NN_TILE = 1024;
 __global__ __launch_bounds__(BLK) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
@@ -367,6 +419,16 @@ MCP_EXPORT int mcp_ball_query(int b, int n, int m, float radius, int nsample, co
     const float radius2 = radius * radius;  // ball_query_gpu.cu:20
     hipLaunchKernelGGL(ball_query_kernel, dim3(mcp_divup(m, BQ_WAVES), b), dim3(64 * BQ_WAVES), 0, (hipStream_t)stream, n, m, radius2,
                        nsample, new_xyz, xyz, idx);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_query_and_group(int b, int n, int m, int c, float radius, int nsample, int use_xyz, const float *xyz, const float *new_xyz,
+                                   const float *features, float *out, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && m > 0 && nsample > 0 && xyz && new_xyz && out && (features ? c > 0 : use_xyz != 0));
+    if (nsample > 64) return MCP_ERR_UNSUPPORTED;
+    const float radius2 = radius * radius;  // ball_query_gpu.cu:20
+    hipLaunchKernelGGL(query_and_group_kernel, dim3(mcp_divup(m, BQ_WAVES), b), dim3(64 * BQ_WAVES), 0, (hipStream_t)stream, n, m, c, radius2,
+                       nsample, (use_xyz || !features) ? 3 : 0, xyz, new_xyz, features, out);
     return mcp_launch_status();
 }
 

@@ -165,45 +165,55 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 class QueryAndGroup(nn.Module):
-    """pointnet2_utils.py:231-264."""
+    """Ball query + grouping of coordinates (relative to the centre) and features: the module of pointnet2/pointnet2_utils.py:231-264.
+    xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N) or None -> (B, 3+C | C | 3, npoint, nsample).
+    Inference takes ONE launch (mcp_query_and_group: the hits of a centre never leave the compute unit, no transposed copy of the
+    cloud, no concatenation); when a gradient is wanted the result is composed from the differentiable functions above."""
 
     def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+        if features is None and not self.use_xyz:
+            raise AssertionError("QueryAndGroup without features needs use_xyz=True: there would be nothing to group")
+        with_xyz = self.use_xyz or features is None
+        if self.nsample <= 64 and not _wants_grad(xyz, new_xyz, features):
+            from . import _lib
+            xyz, new_xyz = xyz.detach().contiguous(), new_xyz.detach().contiguous()
+            feats = None if features is None else features.detach().contiguous()
+            B, N, _ = xyz.shape
+            M = new_xyz.shape[1]
+            C = 0 if feats is None else feats.shape[1]
+            out = torch.empty((B, (3 if with_xyz else 0) + C, M, self.nsample), dtype=torch.float32, device=xyz.device)
+            with torch.cuda.device(xyz.device):
+                _lib.check(_lib.load().mcp_query_and_group(B, N, M, C, float(self.radius), int(self.nsample), int(bool(self.use_xyz)),
+                                                           _lib.fptr(xyz), _lib.fptr(new_xyz), None if feats is None else _lib.fptr(feats),
+                                                           _lib.fptr(out), torch.cuda.current_stream(xyz.device).cuda_stream))
+            return out
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        xyz_trans = xyz.transpose(1, 2).contiguous()
-        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, nsample)
-        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        parts = []
+        if with_xyz:  # neighbour coordinates relative to their centre, channel-major as grouping_operation returns them
+            parts.append(grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1))
         if features is not None:
-            grouped_features = grouping_operation(features, idx)
-            if self.use_xyz:
-                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
-            else:
-                new_features = grouped_features
-        else:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            new_features = grouped_xyz
-        return new_features
+            parts.append(grouping_operation(features, idx))
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
 class GroupAll(nn.Module):
-    """pointnet2_utils.py:267-290."""
+    """The whole cloud as one group (pointnet2/pointnet2_utils.py:267-290): (B, 3+C | C | 3, 1, N); new_xyz is ignored."""
 
     def __init__(self, use_xyz: bool = True):
         super().__init__()
         self.use_xyz = use_xyz
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
-        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        parts = [xyz.transpose(1, 2).unsqueeze(2)] if (self.use_xyz or features is None) else []
         if features is not None:
-            grouped_features = features.unsqueeze(2)
-            if self.use_xyz:
-                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
-            else:
-                new_features = grouped_features
-        else:
-            new_features = grouped_xyz
-        return new_features
+            parts.append(features.unsqueeze(2))
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)

@@ -474,6 +474,26 @@ def test_grouping_modules_match_reference_classes(golden_dir):
         pu.QueryAndGroup(1.0, 8, use_xyz=False)(mi["xyz"], mi["new_xyz"], None)
 
 
+@pytest.mark.parametrize("r,ns", [(0.7, 12), (1.5, 24), (3.0, 64), (0.05, 8)])
+def test_query_and_group_one_launch_equals_the_composed_functions(r, ns):
+    """mcp_query_and_group (inference: one launch) against the differentiable composition ball_query + grouping_operation x 2 +
+    subtraction + cat of the same module, bit for bit -- any nsample up to 64 (not only powers of two), empty balls included
+    (r = 0.05: most centres group point 0 only through the no-hit rule) -- and the composed form carries the gradient."""
+    xyz = cloud(61, 2, 3000).to(DEV)
+    new_xyz = (xyz[:, ::7] + 0.01).contiguous()
+    feats = torch.randn(2, 10, 3000, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    mod = pu.QueryAndGroup(r, ns)
+    fused = mod(xyz, new_xyz, feats)
+    f2 = feats.clone().requires_grad_(True)
+    composed = mod(xyz, new_xyz, f2)
+    assert composed.requires_grad and fused.shape == (2, 13, new_xyz.shape[1], ns)
+    assert torch.equal(fused, composed.detach())
+    (g,) = torch.autograd.grad(composed.sum(), f2)
+    assert g.shape == feats.shape and torch.isfinite(g).all() and float(g.sum()) == float(2 * new_xyz.shape[1] * ns * 10)
+    assert torch.equal(pu.QueryAndGroup(r, ns)(xyz, new_xyz, None), mod(xyz.clone().requires_grad_(True), new_xyz, None).detach())
+    assert torch.equal(pu.QueryAndGroup(r, ns, use_xyz=False)(xyz, new_xyz, feats), composed.detach()[:, 3:])
+
+
 def test_models_common_aliases_match_oracle():
     """The `models.common` names models/layers.py:15,35,37,62,64,162,170 imports (the reference does not ship that module):
     fps, gather_points, ball_query, three_nn, three_interpolate, group_points, bound by compat.install()."""
