@@ -88,6 +88,20 @@ int mcp_group_points(int b, int c, int n, int npoints, int nsample, const float 
 int mcp_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
                           float *grad_points, mcp_stream_t stream);
 
+/* Deterministic forms of the three scatter-add backwards (the reference's kernels -- and the three *_grad entry
+ * points above and below, which keep its exact argument lists -- use atomicAdd: sampling_gpu.cu:46-83, group_points_gpu.cu:8-44,
+ * interpolate_gpu.cu:120-161).  The caller passes, per batch element, the stable sort of the T scatter positions by destination:
+ * order (B,T) int32 = positions in sorted order, seg (B,N+1) int32 = CSR offsets of each destination in it.  Each destination's
+ * addends are summed in ascending position order (a sequential loop's order): the same bits on every run; grad_points needs no
+ * zero-fill.
+ *   mcp_group_points_grad_sorted: grad_out (B,C,T) -> grad_points (B,C,N).  K6 with T = npoints*nsample, K3 with T = npoints.
+ *   mcp_three_interpolate_grad_sorted: grad_out (B,C,n), weight (B,n,3), positions t = 3*p + k of idx (B,n,3) sorted by idx value
+ *     (order (B,3n), seg (B,m+1)) -> grad_points (B,C,m). */
+int mcp_group_points_grad_sorted(int b, int c, int n, int t, const float *grad_out, const int *order, const int *seg,
+                                 float *grad_points, mcp_stream_t stream);
+int mcp_three_interpolate_grad_sorted(int b, int c, int n, int m, const float *grad_out, const int *order, const int *seg,
+                                      const float *weight, float *grad_points, mcp_stream_t stream);
+
 /* ball_query_wrapper(b,n,m,radius,nsample,new_xyz,xyz,idx)   ball_query.cpp:16-28, ball_query_gpu.cu:9-67
  * new_xyz (B,M,3) centres, xyz (B,N,3) -> idx (B,M,nsample), pre-zeroed by the caller
  * (pointnet2_utils.py:218): first nsample hits in index order, padded with the first hit. */

@@ -26,6 +26,8 @@ SIGNATURES = {
     "mcp_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_group_points": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_group_points_grad": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "mcp_group_points_grad_sorted": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_three_interpolate_grad_sorted": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "mcp_ball_query": [_i, _i, _i, _f, _i, _p, _p, _p, _p],
     "mcp_query_and_group": [_i, _i, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p],
     "mcp_three_nn": [_i, _i, _i, _p, _p, _p, _p, _p],

@@ -64,6 +64,35 @@ __global__ __launch_bounds__(BLK) void group_points_grad_kernel(int c, int n, in
     for (int ci = c0; ci < c1; ++ci) atomicAdd(pb + (size_t)ci * n + dst, gb[(size_t)ci * sk + e]);
 }
 
+// Deterministic K3 / K6 / K9: the channel-major scatter-adds of the reference API as segmented reductions.  The
+// caller sorts the T scatter positions of a batch element by destination (stable: equal destinations keep ascending position order)
+// and passes the permutation `order` (B,T) and the CSR offsets seg (B,N+1).  One thread per (destination, channel) sums its segment
+// in that order -- the order of a sequential loop over the positions, so the result equals the oracle's loop bit for bit, on every
+// run; no atomics, no pre-zeroing.  WEIGHTED (K9): position t = 3 * p + k scatters grad_out[.., p] * weight[b, p, k].
+template <bool WEIGHTED>
+__global__ __launch_bounds__(BLK) void scatter_cm_sorted_kernel(int c, int n, int t, int src_n, const float *__restrict__ grad_out,
+                                                                const int *__restrict__ order, const int *__restrict__ seg,
+                                                                const float *__restrict__ weight, float *__restrict__ grad_points) {
+    const int b = blockIdx.z;
+    const int d = blockIdx.x * BLK + threadIdx.x;   // destination point: consecutive threads write consecutive floats
+    if (d >= n) return;
+    const int c0 = blockIdx.y * CCH;
+    const int c1 = min(c, c0 + CCH);
+    const int *sg = seg + (size_t)b * (n + 1) + d;
+    const int lo = sg[0], hi = sg[1];
+    const int *ord = order + (size_t)b * t;
+    const float *wb = WEIGHTED ? weight + (size_t)b * t : nullptr;
+    for (int ci = c0; ci < c1; ++ci) {
+        const float *src = grad_out + ((size_t)b * c + ci) * src_n;
+        float acc = 0.f;
+        for (int j = lo; j < hi; ++j) {
+            const int pos = ord[j];
+            acc += WEIGHTED ? src[pos / 3] * wb[pos] : src[pos];
+        }
+        grad_points[((size_t)b * c + ci) * n + d] = acc;
+    }
+}
+
 // Channel-last row gather: out[b,t,:] = points[b, idx[b,t], :]   (index_points_group, mocopci.py:1204-1215)
 template <typename VT, int VW>
 __global__ __launch_bounds__(BLK) void group_rows_kernel(int n, int cv, long long total, int t, const VT *__restrict__ points,
@@ -353,6 +382,22 @@ MCP_EXPORT int mcp_group_points_grad(int b, int c, int n, int npoints, int nsamp
     const int sk = npoints * nsample;
     hipLaunchKernelGGL(group_points_grad_kernel, dim3(mcp_divup(sk, BLK), mcp_divup(c, CCH), b), dim3(BLK), 0, (hipStream_t)stream,
                        c, n, sk, grad_out, idx, grad_points);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_group_points_grad_sorted(int b, int c, int n, int t, const float *grad_out, const int *order, const int *seg,
+                                            float *grad_points, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && c > 0 && n > 0 && t > 0 && grad_out && order && seg && grad_points);
+    hipLaunchKernelGGL(scatter_cm_sorted_kernel<false>, dim3(mcp_divup(n, BLK), mcp_divup(c, CCH), b), dim3(BLK), 0, (hipStream_t)stream, c, n, t, t,
+                       grad_out, order, seg, nullptr, grad_points);
+    return mcp_launch_status();
+}
+
+MCP_EXPORT int mcp_three_interpolate_grad_sorted(int b, int c, int n, int m, const float *grad_out, const int *order, const int *seg,
+                                                 const float *weight, float *grad_points, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && c > 0 && n > 0 && m > 0 && grad_out && order && seg && weight && grad_points);
+    hipLaunchKernelGGL(scatter_cm_sorted_kernel<true>, dim3(mcp_divup(m, BLK), mcp_divup(c, CCH), b), dim3(BLK), 0, (hipStream_t)stream, c, m, 3 * n, n,
+                       grad_out, order, seg, weight, grad_points);
     return mcp_launch_status();
 }
 

@@ -28,8 +28,24 @@ def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     return _call("mcp_gather_points", points, b, c, n, npoints, _lib.fptr(points), _lib.iptr(idx), _lib.fptr(out))
 
 
+def _segments(idx, n):
+    """Stable sort of the scatter positions of every batch element by destination: (order (B,T) int32, seg (B,n+1) int32 CSR
+    offsets).  Scratch comes from torch's allocator here, in the wrapper -- the library itself never allocates."""
+    B = idx.shape[0]
+    keys, order = torch.sort(idx.reshape(B, -1), dim=1, stable=True)
+    bounds = torch.arange(n + 1, device=idx.device, dtype=keys.dtype).expand(B, n + 1).contiguous()
+    seg = torch.searchsorted(keys.contiguous(), bounds).int()
+    return order.int().contiguous(), seg.contiguous()
+
+
+# The three backward scatters: the reference's kernels add with atomicAdd (sampling_gpu.cu:46-83, group_points_gpu.cu:8-44,
+# interpolate_gpu.cu:120-161), so their sums depend on the order the hardware serves the atomics in.  These wrappers keep the
+# reference's argument lists and results (grad_points is overwritten with the full sum; the reference adds into the caller's
+# zeros) but reduce each destination's addends in ascending position order: bit-reproducible (SURVEY 8(f) #3).
 def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
-    return _call("mcp_gather_points_grad", grad_out, b, c, n, npoints, _lib.fptr(grad_out), _lib.iptr(idx), _lib.fptr(grad_points))
+    order, seg = _segments(idx, n)
+    return _call("mcp_group_points_grad_sorted", grad_out, b, c, n, npoints, _lib.fptr(grad_out), _lib.iptr(order), _lib.iptr(seg),
+                 _lib.fptr(grad_points))
 
 
 def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
@@ -37,7 +53,8 @@ def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
 
 
 def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
-    return _call("mcp_group_points_grad", grad_out, b, c, n, npoints, nsample, _lib.fptr(grad_out), _lib.iptr(idx),
+    order, seg = _segments(idx, n)
+    return _call("mcp_group_points_grad_sorted", grad_out, b, c, n, npoints * nsample, _lib.fptr(grad_out), _lib.iptr(order), _lib.iptr(seg),
                  _lib.fptr(grad_points))
 
 
@@ -54,5 +71,6 @@ def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
 
 
 def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
-    _call("mcp_three_interpolate_grad", grad_out, b, c, n, m, _lib.fptr(grad_out), _lib.iptr(idx), _lib.fptr(weight),
+    order, seg = _segments(idx, m)
+    _call("mcp_three_interpolate_grad_sorted", grad_out, b, c, n, m, _lib.fptr(grad_out), _lib.iptr(order), _lib.iptr(seg), _lib.fptr(weight),
           _lib.fptr(grad_points))

@@ -80,17 +80,44 @@ def test_gather_group_and_grads():
     assert torch.equal(pu.gather_operation(feats.to(DEV), idx.to(DEV)).cpu(), orc.gather_operation(feats, idx))
     gidx = torch.randint(0, 500, (2, 60, 9), generator=g, dtype=torch.int32)
     assert torch.equal(pu.grouping_operation(feats.to(DEV), gidx.to(DEV)).cpu(), orc.grouping_operation(feats, gidx))
-    # backward = scatter-add (atomics: order differs, compare with tolerance)
+    # backward = scatter-add as a segmented reduction in ascending position order (round 4): the oracle's sequential loop, bit for bit
     f = feats.to(DEV).requires_grad_(True)
     out = pu.grouping_operation(f, gidx.to(DEV))
     go = torch.randn(out.shape, generator=g)
     out.backward(go.to(DEV))
-    torch.testing.assert_close(f.grad.cpu(), orc.grouping_operation_grad(go, gidx, 500), rtol=1e-5, atol=1e-5)
+    assert torch.equal(f.grad.cpu(), orc.grouping_operation_grad(go, gidx, 500))
     f2 = feats.to(DEV).requires_grad_(True)
     out = pu.gather_operation(f2, idx.to(DEV))
     go = torch.randn(out.shape, generator=g)
     out.backward(go.to(DEV))
-    torch.testing.assert_close(f2.grad.cpu(), orc.gather_operation_grad(go, idx, 500), rtol=1e-5, atol=1e-5)
+    assert torch.equal(f2.grad.cpu(), orc.gather_operation_grad(go, idx, 500))
+
+
+def test_reference_api_backward_scatters_are_deterministic_and_exact():
+    """K3 / K6 / K9 behind the reference's autograd functions: heavy collisions (every destination hit ~250 times), five runs give the
+    same bits, and those bits are the oracle's sequential loop (pointnet2_oracle.c: positions ascending)."""
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(2, 33, 64, generator=g)
+    gidx = torch.randint(0, 64, (2, 500, 32), generator=g, dtype=torch.int32)
+    go = torch.randn(2, 33, 500, 32, generator=g)
+    runs = []
+    for _ in range(5):
+        f = feats.to(DEV).requires_grad_(True)
+        pu.grouping_operation(f, gidx.to(DEV)).backward(go.to(DEV))
+        runs.append(f.grad.clone())
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    assert torch.equal(runs[0].cpu(), orc.grouping_operation_grad(go, gidx, 64))
+    # K9: three_interpolate backward, 3 weighted addends per unknown point
+    idx3 = torch.randint(0, 64, (2, 4000, 3), generator=g, dtype=torch.int32)
+    w3 = torch.rand(2, 4000, 3, generator=g)
+    go3 = torch.randn(2, 33, 4000, generator=g)
+    runs = []
+    for _ in range(3):
+        f = feats.to(DEV).requires_grad_(True)
+        pu.three_interpolate(f, idx3.to(DEV), w3.to(DEV)).backward(go3.to(DEV))
+        runs.append(f.grad.clone())
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    assert torch.equal(runs[0].cpu(), orc.three_interpolate_grad(go3, idx3, w3, 64))
 
 
 @pytest.mark.parametrize("radius,nsample", [(0.5, 16), (1.0, 16), (2.0, 8), (4.0, 8), (1e-4, 4)])
