@@ -173,6 +173,150 @@ __global__ __launch_bounds__(64 * WAVES) void knn_cosine_kernel(int q, int n, in
     mcp_store_list<K>(a, kout, oi, od);
 }
 
+// Round 4: the same search with the reference range split over the RS waves of a workgroup and NO shared tile.  Round 3's kernel gave a
+// workgroup 128 queries and walked every reference with them: 1024 waves at level 1 (one per SIMD, nothing to overlap the selection
+// with), 256 and 128 waves at levels 2 / 3 -- a quarter and an eighth of the chip, 83 / 71 us for 7 / 3 us of matrix work.  Here a
+// workgroup owns 32 queries; wave r takes the reference tiles r, r + RS, ... and reads its A operand straight from global memory
+// (a lane needs the channels of ITS reference row with its own parity: eight 16-byte loads per 32 channels, both lane halves hit the
+// same lines, the next 32 channels are in flight while the 16 MFMAs of these run) -- no LDS tile, no workgroup barrier in the loop;
+// the RS partial lists meet in LDS at the end.  The k-ordered fp32 fma chain per (query, reference) and the (distance, index) order
+// are unchanged, so the indices are the same bits.
+template <int C, int RS>
+__global__ __launch_bounds__(64 * RS) void knn_cosine_split_kernel(int q, int n, int kout, const float *__restrict__ nq,
+                                                                   const float *__restrict__ nr, int *__restrict__ idx,
+                                                                   float *__restrict__ dist) {
+    constexpr int CH = C / 32;                   // chunks of 32 channels (16 k-steps) per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    uint2(*queue)[64] = reinterpret_cast<uint2(*)[64]>(smem) + (size_t)wave * QS;
+
+    const int b = blockIdx.y;
+    const int qi = blockIdx.x * 32 + col;
+    const bool live = qi < q;
+    const float *qrow = nq + ((size_t)b * q + (live ? qi : 0)) * C;
+    float bq[C / 2];   // channel parity h of the query's row: whole 16-byte loads, two of the four floats kept
+#pragma unroll
+    for (int j = 0; j < C / 4; ++j) {
+        const float4 v = reinterpret_cast<const float4 *>(qrow)[j];
+        bq[2 * j] = h ? v.y : v.x;
+        bq[2 * j + 1] = h ? v.w : v.z;
+    }
+    nr += (size_t)b * n * C;
+
+    u64 a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = KEY_INF;
+    float tau = INFINITY;
+    int cnt = 0;
+    auto flush = [&]() {
+        mcp_flush_queue<K, QS>(a, queue, lane, cnt);
+        tau = mcp_tau_of(a[K - 1]);
+        cnt = 0;
+    };
+
+    const int ntiles = (n + RT - 1) / RT;
+    const int mine = wave < ntiles ? (ntiles - wave + RS - 1) / RS : 0;   // tiles wave, wave + RS, ...
+    // a lane reads its own reference row (clamped at the end of the cloud: those rows are skipped in the selection)
+    auto load = [&](int t, int c, float4 (&v)[8]) {
+        const int row = min(t * RT + col, n - 1);
+        const float4 *p = reinterpret_cast<const float4 *>(nr + (size_t)row * C + c * 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[j];
+    };
+    f32x16 acc;
+    auto mfma16 = [&](int c, const float4 (&v)[8]) {   // c is a compile-time constant at every call (unrolled chunk loop): bq stays in registers
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // channels 4j .. 4j+3 of the chunk = k-steps 2j (channels 4j, 4j+1) and 2j+1 (4j+2, 4j+3); lane half h holds channel parity h
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[j].y : v[j].x, bq[c * 16 + 2 * j], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[j].w : v[j].z, bq[c * 16 + 2 * j + 1], acc, 0, 0, 0);
+        }
+    };
+    float4 va[8], vb[8];
+    if (mine > 0) load(wave, 0, va);
+    for (int ti = 0; ti < mine; ++ti) {
+        const int t = wave + ti * RS;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; c += 2) {   // two register sets take turns: the next 32 channels are in flight under these 16 MFMAs
+            load(t, c + 1, vb);
+            mfma16(c, va);
+            if (c + 2 < CH) load(t, c + 2, va);
+            else if (ti + 1 < mine) load(t + RS, 0, va);
+            mfma16(c + 1, vb);
+        }
+        const int base = t * RT;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += CHK) {
+#pragma unroll
+            for (int r = r0; r < r0 + CHK; ++r) {
+                const int ri = base + chan_of(r, h);
+                const float d = 1.0f - acc[r];
+                if (ri < n && d < tau) {
+                    queue[cnt][lane] = make_uint2(__float_as_uint(d), (uint32_t)ri);
+                    ++cnt;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(cnt > QS - CHK)) flush();
+        }
+    }
+    flush();
+    // merge the two lane halves of each query
+    u64 o[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t lo = __shfl_xor(mcp_key_lo(a[j]), 32), hi = __shfl_xor(mcp_key_hi(a[j]), 32);
+        o[j] = mcp_key_words(hi, lo);
+    }
+    mcp_merge_sorted<K, K>(a, o);
+    // ... and the RS reference parts: waves 1.. park their lists in LDS (their own queue space: K = QS slots of 64 lanes), wave 0 merges
+    __syncthreads();
+    if (wave > 0 && h == 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) queue[j][col] = make_uint2(mcp_key_lo(a[j]), mcp_key_hi(a[j]));
+    }
+    __syncthreads();
+    if (wave != 0 || h) return;
+    for (int w = 1; w < RS; ++w) {
+        uint2(*other)[64] = reinterpret_cast<uint2(*)[64]>(smem) + (size_t)w * QS;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint2 e = other[j][col];
+            o[j] = mcp_key_words(e.y, e.x);
+        }
+        mcp_merge_sorted<K, K>(a, o);
+    }
+    if (!live) return;
+    int *oi = idx + ((size_t)b * q + qi) * kout;
+    float *od = dist ? dist + ((size_t)b * q + qi) * kout : nullptr;
+    mcp_store_list<K>(a, kout, oi, od);
+}
+
+template <int C, int RS>
+int launch_cosine_split(int b, int q, int n, int k, const float *nq, const float *nr, int *idx, float *dist, hipStream_t s) {
+    static_assert(K == QS && (C / 32) % 2 == 0, "the partial lists reuse the queues; chunks are consumed in pairs");
+    const size_t lds = (size_t)RS * QS * 64 * sizeof(uint2);
+    auto kern = knn_cosine_split_kernel<C, RS>;
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
+        attr_once.done();
+    }
+    hipLaunchKernelGGL(kern, dim3(mcp_divup(q, 32), b), dim3(64 * RS), lds, s, q, n, k, nq, nr, idx, dist);
+    return mcp_launch_status();
+}
+
+// reference parts per workgroup: enough waves to cover the chip's 1024 SIMDs twice where the problem allows it
+template <int C>
+int launch_cosine_auto(int b, int q, int n, int k, const float *nq, const float *nr, int *idx, float *dist, hipStream_t s) {
+    const long long groups = (long long)b * ((q + 31) / 32);
+    const int tiles = (n + RT - 1) / RT;
+    if (groups * 2 >= 2048 || tiles < 4) return launch_cosine_split<C, 2>(b, q, n, k, nq, nr, idx, dist, s);
+    if (groups * 4 >= 2048 || tiles < 8) return launch_cosine_split<C, 4>(b, q, n, k, nq, nr, idx, dist, s);
+    return launch_cosine_split<C, 8>(b, q, n, k, nq, nr, idx, dist, s);
+}
+
 template <int C>
 int launch_cosine(int b, int q, int n, int k, const float *nq, const float *nr, int *idx, float *dist, hipStream_t s) {
     const size_t lds = (size_t)2 * RT * (C + 1) * sizeof(float) + (size_t)WAVES * QS * 64 * sizeof(uint2);
@@ -188,6 +332,11 @@ int launch_cosine(int b, int q, int n, int k, const float *nq, const float *nr, 
 
 }  // namespace
 
+#ifdef MCP_AB
+static int g_cosine_use_old = 0;   // A/B builds only: 1 = round 3's shared-tile kernel
+extern "C" __attribute__((visibility("default"))) void mcp_knn_cosine_use_old(int on) { g_cosine_use_old = on; }
+#endif
+
 MCP_EXPORT int mcp_knn_cosine(int b, int q, int n, int c, int k, const float *qfeat, const float *rfeat, int *idx, float *dist,
                               float *workspace, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && q > 0 && n > 0 && c > 0 && k > 0 && qfeat && rfeat && idx && workspace);
@@ -202,9 +351,16 @@ MCP_EXPORT int mcp_knn_cosine(int b, int q, int n, int c, int k, const float *qf
     else launch_normalize<256>(rq, qfeat, nq, rr, rfeat, nr, s);
     int rc = mcp_launch_status();
     if (rc == MCP_OK) {
-        rc = c == 64    ? launch_cosine<64>(b, q, n, k, nq, nr, idx, dist, s)
-             : c == 128 ? launch_cosine<128>(b, q, n, k, nq, nr, idx, dist, s)
-                        : launch_cosine<256>(b, q, n, k, nq, nr, idx, dist, s);
+#ifdef MCP_AB
+        if (g_cosine_use_old)
+            rc = c == 64    ? launch_cosine<64>(b, q, n, k, nq, nr, idx, dist, s)
+                 : c == 128 ? launch_cosine<128>(b, q, n, k, nq, nr, idx, dist, s)
+                            : launch_cosine<256>(b, q, n, k, nq, nr, idx, dist, s);
+        else
+#endif
+        rc = c == 64    ? launch_cosine_auto<64>(b, q, n, k, nq, nr, idx, dist, s)
+             : c == 128 ? launch_cosine_auto<128>(b, q, n, k, nq, nr, idx, dist, s)
+                        : launch_cosine_auto<256>(b, q, n, k, nq, nr, idx, dist, s);
     }
     mcp_prof_end(MCP_KERNEL_KNN_COSINE, s);
     return rc;
