@@ -28,7 +28,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import grad, ops
+from . import grad, ops, schedule
+from .schedule import Schedule
 
 _SPEC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "state_dict_spec.json")
 LEAKY = 0.1  # mocopci.py:1107, pointconv_util.py:10
@@ -63,41 +64,6 @@ def _dtype(name):
     return getattr(torch, name)
 
 
-class Early:
-    """Results that depend only on encoder outputs (EI cross-formers, feature-cosine searches, the level-0 interpolation
-    search) are issued on a third stream the moment their inputs exist; the small-kernel stages of the encoder's lower levels
-    and of the decoder's levels 3 and 2 leave most of the chip idle, and these branches fill it.  get() makes the caller's
-    stream wait for the one result it is about to read.  Without a GPU stream (CPU backends) everything runs inline."""
-
-    def __init__(self, model, device):
-        self.model, self.device = model, device
-        self.items = {}
-
-    def launch(self, key, fn, lane=1):
-        """lane: which extra stream (one per pyramid level, so a level's branches never queue behind another level's)."""
-        aux = self.model.side_stream(self.device, lane)
-        if aux is None:
-            self.items[key] = (fn(), None)
-            return
-        aux.wait_stream(torch.cuda.current_stream(self.device))  # inputs were produced on the launching stream
-        with torch.cuda.stream(aux):
-            res = fn()
-            ev = torch.cuda.Event()
-            ev.record(aux)
-        self.items[key] = (res, ev)
-
-    def get(self, key):
-        """The READING stream (whichever is current: the encoder may run on a stream of its own, the decoder reads) waits for the
-        result and is recorded as a user of its memory."""
-        res, ev = self.items[key]
-        if ev is not None:
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(ev)
-            for t in (res if isinstance(res, (tuple, list)) else (res,)):
-                t.record_stream(cur)
-        return res
-
-
 class MoCoPCI(nn.Module):
     T_F = [0.0, 0.41666666666666663, 0.5, 0.5833333333333333, 1.0]  # mocopci.py:824
     T_B = [1.0, 0.5833333333333333, 0.5, 0.41666666666666663, 0.0]  # mocopci.py:825
@@ -109,7 +75,8 @@ class MoCoPCI(nn.Module):
     BN_MOMENTUM = 0.1       # nn.BatchNorm default
     PAIR_CFA = True         # inference: cross_block3 evaluated once for both decoder directions (it is symmetric in its two frames)
     LANE_MAP = None         # side lanes folded onto fewer HIP streams, e.g. (0, 1, 1, 1, 0, 0) (experiments with several caller streams: tools/two_stream.py)
-    SIDE_PROJECTIONS = True # decoder levels 2 / 1: the feature-only chain in front of Multiframe_Attention on a side lane (A/B switch)
+    NODE_LANES = schedule.NODE_LANES   # which side lane each independent chain of a forward runs on (data: tools/lane_order.py sweeps it)
+    SIDE_PROJECTIONS = True # the decoder's feature-only chains on side lanes (A/B switch: False runs schedule.SIDE_PROJECTION_NODES inline)
     FUSE_POINTCONV = True  # PointConv's Linear inside the grouped kernel where it is built for the shape (A/B switch)
     FOLD_EI = True          # inference: EI cross-formers in their folded 9-launch form (A/B: tools/step_time.py net.FOLD_EI=0)
 
@@ -364,7 +331,7 @@ class MoCoPCI(nn.Module):
     def side_stream(self, device, which=0):
         """Extra HIP streams beside the caller's.  0: the encoder's serial FPS chains (one workgroup per batch element, latency-
         bound), which overlap with the KNN / PointConv work of the main stream.  1-3: branches that depend only on encoder
-        features (see Early).  4: the level-0 self search.  5: the refinement stage's FPS (a lane of its own: the NEXT batch's
+        features (schedule.NODE_LANES).  4: the level-0 self search.  5: the refinement stage's FPS (a lane of its own: the NEXT batch's
         pyramid may already be queued on lane 0).  One set per caller stream, so forwards issued on different streams stay
         independent.  CPU backends run inline."""
         if device.type != "cuda" or self._live is not None:  # a training forward runs on one stream (autograd replays it in order)
@@ -377,92 +344,57 @@ class MoCoPCI(nn.Module):
             sides[key] = torch.cuda.Stream(device=device)
         return sides[key]
 
-    def sample_pyramid(self, xyz, side):
-        """The four FPS levels (mocopci.py:445-463) issued on the side stream: they depend only on the coordinates.  Returns
-        ([xyz, pc1..pc4], sel1, {level: ready event}); the caller's stream waits for a level only where it first reads it."""
-        main = torch.cuda.current_stream(xyz.device)
-        ready = {}
-        with torch.cuda.stream(side):
-            pcs = [xyz]
-            sel1 = None
-            for lvl, npoint in enumerate((2048, 512, 256, 64), start=1):
-                pts, sel = self.fps_gather(pcs[-1], npoint, return_idx=True)
-                pcs.append(pts)
-                sel1 = sel if lvl == 1 else sel1
-                ready[lvl] = torch.cuda.Event()
-                ready[lvl].record(side)
-            # the sampled clouds in the decoder's "other frame" arrangement (levels 1..3): three small copies that ride along here,
-            # off the main stream and off the lanes the feature branches queue on
-            half = xyz.shape[0] // 2
-            swapped = {lvl: torch.cat([pcs[lvl][half:], pcs[lvl][:half]], dim=0) for lvl in (1, 2, 3)}
-            ready["swapped"] = torch.cuda.Event()
-            ready["swapped"].record(side)
-        for t in (*pcs[1:], sel1, *swapped.values()):  # allocated on the side stream, consumed on the main stream
-            t.record_stream(main)
-        ready["swapped_clouds"] = swapped
-        return pcs, sel1, ready
+    def issue_inputs_only(self, sched, xyz_fn, after=None):
+        """Everything of a forward that depends on nothing but the inputs, as schedule nodes: the channel-last layout ("xyz"), the four
+        FPS levels (mocopci.py:445-463; ("pc", level)), the sampled clouds in the decoder's "other frame" arrangement ("swap_pc") and
+        the level-0 self search.  after: see Schedule.run (prefetch() issues these behind the inputs' event, a plain forward behind
+        the caller's stream)."""
+        sched.run("xyz", xyz_fn, after=after)
+        chained = None if after is None else ()   # behind the layout: stream order on the same lane / inline
 
-    def early_self_search(self, xyz, laid_out, main):
-        """knn(xyz, xyz, 32) of the stacked input clouds on a lane of its own, behind the event after which xyz is laid out.
-        Returns (idx0, event)."""
-        lane = self.side_stream(xyz.device, 4)
-        lane.wait_event(laid_out)
-        with torch.cuda.stream(lane):
-            idx0 = ops.backend().knn(xyz, xyz, 32)
-            found = torch.cuda.Event()
-            found.record(lane)
-        xyz.record_stream(lane)
-        idx0.record_stream(main)
-        return idx0, found
+        def level(lvl, npoint):
+            src = sched.peek("xyz") if lvl == 1 else sched.peek(("pc", lvl - 1))[0]
+            return self.fps_gather(src, npoint, return_idx=True)        # (points, indices)
+        for lvl, npoint in enumerate((2048, 512, 256, 64), start=1):
+            sched.run(("pc", lvl), lambda lvl=lvl, npoint=npoint: level(lvl, npoint), after=chained)
 
-    def run_encoder(self, xyz, early=None, pyramid=None, self_search=None):
-        """PointConvEncoder.forward (mocopci.py:438-468), color == xyz.  The four FPS levels depend only on the
-        coordinates, so the whole sampling pyramid is issued up front on the side stream.  pyramid: the result of
-        sample_pyramid when the caller already issued it (forward(inputs_ready=...): it then ran under the PREVIOUS call's tail,
-        so level 1 is not speculated).  self_search: (idx0, ready event) when the caller issued the level-0 self search the
-        same way (it, too, depends on nothing but the inputs)."""
+        def swapped():  # three small copies that ride along here, off the main stream and off the lanes the feature branches queue on
+            half = sched.peek("xyz").shape[0] // 2
+            return {lvl: torch.cat([sched.peek(("pc", lvl))[0][half:], sched.peek(("pc", lvl))[0][:half]], dim=0) for lvl in (1, 2, 3)}
+        sched.run("swap_pc", swapped, after=chained)
+        # the level-0 self search (0.6 ms with its sorted cloud) on a lane of its own: it neither delays the sampling chain nor waits for it
+        xyz = sched.peek("xyz")
+        sched.run("self_search", lambda: ops.backend().knn(xyz, xyz, 32), reads=(xyz,), after=None if after is None else (sched.event("xyz"),))
+
+    def run_encoder(self, xyz, sched=None, speculate=None):
+        """PointConvEncoder.forward (mocopci.py:438-468), color == xyz.  The sampling pyramid and the level-0 self search depend only
+        on the coordinates: they are schedule nodes, issued here unless the caller already did (prefetch(): they then ran under the
+        PREVIOUS call's tail, and level 1 is not speculated).  A level's cloud is fetched where it is first read."""
         p = "encoder."
-        side = self.side_stream(xyz.device)
-        ready = {}
-        speculate = side is not None and pyramid is None
-        if side is not None:
-            main = torch.cuda.current_stream(xyz.device)
-            if pyramid is None:
-                side.wait_stream(main)
-                pyramid = self.sample_pyramid(xyz, side)
-            (_, pc1, pc2, pc3, pc4), sel1, ready = pyramid
-            if early is not None:
-                for lvl, t in ready["swapped_clouds"].items():
-                    early.items[("swap_pc", lvl)] = (t, ready["swapped"])
-        else:
-            pc1, sel1 = self.fps_gather(xyz, 2048, return_idx=True)
-            pc2 = self.fps_gather(pc1, 512)
-            pc3 = self.fps_gather(pc2, 256)
-            pc4 = self.fps_gather(pc3, 64)
-
-        def need(lvl):  # the main stream waits for a level only where it first reads it
-            if side is not None:
-                main.wait_event(ready[lvl])
+        standalone = sched is None   # the encoder alone (tests compare its pyramid / features): none of the decoder's early nodes
+        if standalone:
+            sched = Schedule(self, xyz.device)
+        if speculate is None:
+            speculate = not sched.has("xyz") and sched.lane(("pc", 1)) is not None
+        if not sched.has("xyz"):
+            self.issue_inputs_only(sched, lambda: xyz)
+        pc = lambda lvl: sched.get(("pc", lvl))[0]
 
         self._mark("enc start")
         f0 = self.conv1d_block(xyz, p + "level0_lift")
-        if self_search is not None:
-            idx0, found = self_search
-            torch.cuda.current_stream(xyz.device).wait_event(found)
-        else:
-            idx0 = ops.backend().knn(xyz, xyz, 32)
+        idx0 = sched.get("self_search")
         f0 = self.pointconv(p + "level0", xyz, xyz, f0, idx=idx0)
         f0_1 = self.conv1d_block(f0, p + "level0_1")
         if speculate:
             # The main stream would now wait ~0.6 ms for the level-1 sampling.  Level 1 is a PointConvD whose centres are
             # SAMPLED points of xyz and whose neighbours are rows of the level-0 self search (sampled_neighbours), so its
             # output for every candidate centre can be computed before the sample is known -- 4x the work, on an otherwise
-            # idle chip -- and the sampled rows gathered afterwards (same per-row arithmetic; only the BLAS tiling differs).
+            # idle chip -- and the sampled rows gathered afterwards (same per-row arithmetic, same kernels: lin(like_rows=)).
             f1_all = self.conv1d_block(self.pointconv(p + "level1", xyz, xyz, f0_1, idx=idx0), p + "level1_0")
-            need(1)
+            pc1, sel1 = sched.get(("pc", 1))
             f1 = ops.backend().group_rows(f1_all, sel1)
         else:
-            need(1)
+            pc1, sel1 = sched.get(("pc", 1))
             # level 1 searches the 32 nearest of pc1 = xyz[sel1] in xyz: rows of the level-0 self search
             # (kernels as for all of xyz's rows: the speculative form above computes those, and both must give the same bits)
             like = xyz.shape[0] * xyz.shape[1]
@@ -473,32 +405,32 @@ class MoCoPCI(nn.Module):
         swap = lambda t: torch.cat([t[B:], t[:B]], dim=0)
 
         def branches(lvl, f):  # decoder work that needs nothing but this level's encoder features (both frames stacked)
-            if early is None:
+            if standalone:
                 return
-            early.launch(("swap_f", lvl), lambda: swap(f), lane=lvl)   # the "other frame" arrangement the decoder reads
-            early.launch(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:], stacked=f)), lane=lvl)
+            sched.run(("swap_f", lvl), lambda: swap(f))   # the "other frame" arrangement the decoder reads
+            sched.run(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:], stacked=f)))
             def cos():  # both directions of the feature-space search: the backward one is the forward one with its halves swapped
                 i12 = ops.backend().knn_cosine(f, swap(f), 16)
                 return i12, swap(i12)
-            early.launch(("cos", lvl), cos, lane=lvl)
+            sched.run(("cos", lvl), cos)
 
         branches(1, f1)
-        if early is not None:
-            early.launch("i3_01", lambda: ops.backend().interp3_search(xyz, pc1), lane=1)
+        if not standalone:
+            sched.run("i3_01", lambda: ops.backend().interp3_search(xyz, pc1))
         f1_2 = self.conv1d_block(f1, p + "level1_1")
         self._mark("enc level1 done")
-        need(2)
+        pc2 = pc(2)
         f2 = self.pointconv(p + "level2", pc1, pc2, f1_2)
         f2 = self.conv1d_block(f2, p + "level2_0")
         branches(2, f2)
         f2_3 = self.conv1d_block(f2, p + "level2_1")
         self._mark("enc level2 done (before need 3)")
-        need(3)
+        pc3 = pc(3)
         f3 = self.pointconv(p + "level3", pc2, pc3, f2_3)
         f3 = self.conv1d_block(f3, p + "level3_0")
         f3_4 = self.conv1d_block(f3, p + "level3_1")
         self._mark("enc level3 done (before need 4)")
-        need(4)
+        pc4 = pc(4)
         f4 = self.pointconv(p + "level4", pc3, pc4, f3_4)
         self._mark("enc end")
         return [xyz, pc1, pc2, pc3, pc4], [f0, f1, f2, f3, f4]
@@ -845,7 +777,7 @@ class MoCoPCI(nn.Module):
 
     def multiframe_attention(self, prefix, pc1, pc2, f1_new, f2_new, f1_0, f1_1, f2_0, f2_1, up_frames, time_enc, rows=None, idx_c12=None,
                              projections=None):
-        """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C).  projections: key of an Early result whose last four
+        """Multiframe_Attention.forward (mocopci.py:182-212).  time_enc (B,5,1,C).  projections: schedule node whose result's last four
         members are mfa_projections(...) -- the decoder then ran that feature-only chain on a side lane beside the warp / search chain
         below, which reads only coordinates and flows (f1_new / f2_new are not read here in that case)."""
         b, fe = prefix + ".bid", prefix + ".fe"
@@ -890,7 +822,7 @@ class MoCoPCI(nn.Module):
             members = need if sel is not None else list(range(R * B2))
             bmap = self.batch_map(tuple(i % B2 for i in members), dev)
             if projections is not None:
-                t11_1, t22_2, t11_2, t22_1 = self._early.get(projections)[-4:]
+                t11_1, t22_2, t11_2, t22_1 = self._sched.get(projections)[-4:]
             n1a = self.cross(pc1r, pc2w, t11_1, t22_2, None, None, b + ".pos", bid_mlp, True, idx_c12, bmap=bmap, shared=7)
             n2a = self.cross(pc2w, pc1r, t11_2, t22_1, None, None, b + ".pos", bid_mlp, True, idx_c21, bmap=bmap, shared=7)
             fea = self.cross(pc1r, pc2w, self.lin(n1a, fe + ".conv1"), self.lin(n2a, fe + ".conv2"), None, None, fe + ".pos", fe_mlp,
@@ -1071,50 +1003,45 @@ class MoCoPCI(nn.Module):
         m = "multi_frame_inference."
         dev = pcs[0].device
         sw = lambda t: torch.cat([t[B:], t[:B]], dim=0)                            # swap the two frames
-        # "other" frame, same order (levels 1..3 are the ones read)
-        early = self._early
-        # (the encoder issued these copies off the main stream as soon as their sources existed -- the clouds with the sampling pyramid,
-        # the level-1 / 2 features on their lanes; level 3's features are needed right here and a lane result would make this stream
-        # wait for everything queued in front of it on the shared hardware queue, so that one copy stays on the main stream)
-        got = lambda key, t: early.get(key) if key in early.items else sw(t)
-        class _Other:  # fetched where a level is first read: a get() makes this stream wait for the lane that produced the copy
-            def __init__(self, kind, ts):
-                self.kind, self.ts, self.have = kind, ts, {}
+        sched = self._sched
+        # "other" frame, same order (levels 1..3 are the ones read): the encoder issued these copies off the main stream as soon as
+        # their sources existed -- the clouds with the sampling pyramid, the level-1 / 2 features on their lanes; level 3's features are
+        # needed right here (a lane result would make this stream wait for everything queued in front of it on the shared hardware
+        # queue), so that one copy is made on this stream.  Fetched where a level is first read.
+        class _Other:
+            def __init__(self, fetch):
+                self.fetch, self.have = fetch, {}
 
             def __getitem__(self, i):
                 if i not in self.have:
-                    self.have[i] = got((self.kind, i), self.ts[i])
+                    self.have[i] = self.fetch(i)
                 return self.have[i]
-        pcs_o, feats_o = _Other("swap_pc", pcs), _Other("swap_f", feats)
+        pcs_o = _Other(lambda i: sched.get("swap_pc")[i])
+        feats_o = _Other(lambda i: sched.get(("swap_f", i)) if sched.has(("swap_f", i)) else sw(feats[i]))
         cache = {}
-        side0 = self._live is None and self.SIDE_PROJECTIONS and not train and self.side_stream(dev, 1) is not None
-        if side0:
-            # level 0's stacked inputs (frames 1, 1, 2 for the three interpolated frames) read encoder outputs only: four copies made on
-            # the lane that produced the level-0 interpolation search, long before the main stream wants them
+        if not train:
+            # level 0's stacked inputs (frames 1, 1, 2 for the three interpolated frames) read encoder outputs only: four copies made
+            # beside the level-0 interpolation search, long before this stream wants them
             def rep0():
-                i3_, w3_ = early.get("i3_01")
+                i3_, w3_ = sched.get("i3_01")
                 r3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
                 return r3(pcs[0]), r3(feats[0]), r3(i3_), r3(w3_)
-            early.launch(("rep0",), rep0, lane=1)
+            sched.run("rep0", rep0)
 
-        # EI cross-formers (mocopci.py:830-836): fusion features are shared by both frames
-        # EI cross-formers (mocopci.py:830-836; fusion features shared by both frames), the feature-cosine searches and the
-        # level-0 interpolation search were issued by the encoder as soon as their inputs existed (Early)
-        # (level 3's own are needed right here, so they run inline)
+        # EI cross-formers (mocopci.py:830-836; fusion features shared by both frames), the feature-cosine searches and the level-0
+        # interpolation search were issued by the encoder as soon as their inputs existed; level 3's own are needed right here
         self._mark("dec start")
         up43 = lambda: self.conv1d_block(self.interp(pcs[3], pcs[4], feats[4], cache, "43"), m + "deconv4_3")   # l4 -> l3 (mocopci.py:842-845)
-        side3 = self._live is None and self.SIDE_PROJECTIONS and self.side_stream(dev, 3) is not None
-        if side3:
-            # beside the EI cross-former of level 3 (a row of small launches on this stream), on level 3's own lane: the upsampled level-4
-            # features and cross3's feature-cosine search -- both read encoder outputs only
-            f3o = feats_o[3]
-            early.launch(("up43",), up43, lane=3)
-            early.launch(("cos", 3), lambda: ops.backend().knn_cosine(feats[3], f3o, 16), lane=3)
+        # beside the EI cross-former of level 3 (a row of small launches on this stream): the upsampled level-4 features and cross3's
+        # feature-cosine search -- both read encoder outputs only
+        f3o = feats_o[3]
+        sched.run("up43", up43)
+        sched.run(("cos", 3), lambda: ops.backend().knn_cosine(feats[3], f3o, 16))
         f3 = self.ei_crossformer(m + "ei3", feats[3][:B], feats[3][B:], stacked=feats[3])
         fus = [None, None, None, torch.cat([f3, f3], dim=0)]
 
         self._mark("ei3 done")
-        f_l4_3 = early.get(("up43",)) if side3 else up43()
+        f_l4_3 = sched.get("up43")
         c3 = torch.cat([feats[3], fus[3], f_l4_3], dim=-1)                         # (2B,256,576)
         # cross3 (pointconv_util.py:783-791): rows [:B] give feat1_new, rows [B:] give feat2_new
         x = m + "cross3"
@@ -1122,36 +1049,33 @@ class MoCoPCI(nn.Module):
             # points2 = cross_t22 of the OTHER frame's concatenation: the kernel reads batch element b of the projection from element
             # (b + B) mod 2B through its batch map instead of a swapped copy of the 576-wide input
             swap_map = self.batch_map(tuple((i + B) % (2 * B) for i in range(2 * B)), dev)
-            if side3:  # the two 576 -> 256 projections (library GEMMs, 60 us each at 4096 rows) side by side
-                early.launch(("t22", 3), lambda: self.lin(c3, x + ".cross_t22"), lane=3)
-                t11_3 = self.lin(c3, x + ".cross_t11")
-                t22_3, cos3 = early.get(("t22", 3)), early.get(("cos", 3))
-            else:
-                t11_3, t22_3, cos3 = self.lin(c3, x + ".cross_t11"), self.lin(c3, x + ".cross_t22"), None
-            new3 = self.cross(pcs[3], pcs_o[3], t11_3, t22_3, feats[3], feats_o[3], x + ".pos1", [x + ".mlp1.0"], False, idx_c=cos3,
-                              bmap=swap_map, shared=2)
+            # the two 576 -> 256 projections (library GEMMs, 60 us each at 4096 rows) side by side
+            sched.run(("t22", 3), lambda: self.lin(c3, x + ".cross_t22"))
+            t11_3 = self.lin(c3, x + ".cross_t11")
+            new3 = self.cross(pcs[3], pcs_o[3], t11_3, sched.get(("t22", 3)), feats[3], feats_o[3], x + ".pos1", [x + ".mlp1.0"], False,
+                              idx_c=sched.get(("cos", 3)), bmap=swap_map, shared=2)
         else:
             new3 = self.cross(pcs[3], pcs_o[3], self.lin(c3, x + ".cross_t11"), self.lin(sw(c3), x + ".cross_t22"), feats[3],
-                              feats_o[3], x + ".pos1", [x + ".mlp1.0"], False)
+                              feats_o[3], x + ".pos1", [x + ".mlp1.0"], False, idx_c=sched.get(("cos", 3)))
         if self._live is None:  # the two per-frame Linears as ONE batched product written straight into the stacked layout
             wt, bt = self.derived(("cross3_t12", x), lambda: (torch.stack([self.W(x + ".cross_t1").t(), self.W(x + ".cross_t2").t()]).contiguous(),
                                                                torch.stack([self.Bv(x + ".cross_t1"), self.Bv(x + ".cross_t2")]).unsqueeze(1).contiguous()))
             new3 = torch.baddbmm(bt, new3.reshape(2, -1, new3.shape[-1]), wt).reshape(new3.shape[0], new3.shape[1], -1)
         else:
             new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
-        # Feature-only chains (upsampled features -> deconv -> the four projections of the next Multiframe_Attention) run on the level's
-        # feature lane -- idle since the encoder -- beside the main stream's coordinate chain (cross_block3 / flow upsampling / warp /
-        # searches): both are rows of small launches that leave the chip mostly empty.  The 3-NN search both sides interpolate with is
-        # made first, on this stream.
-        side = self._live is None and self.SIDE_PROJECTIONS and self.side_stream(dev, 2) is not None
-        if side:
+        # Feature-only chains (upsampled features -> deconv -> the four projections of the next Multiframe_Attention) are schedule nodes
+        # of their own -- their lane has been idle since the encoder -- beside this stream's coordinate chain (cross_block3 / flow
+        # upsampling / warp / searches): both are rows of small launches that leave the chip mostly empty.  The 3-NN search both
+        # sides interpolate with is made first, on this stream.
+        proj = self._live is None   # inference: the projections come from the node; a training forward keeps them in its autograd graph here
+        if proj:
             self.interp_prepare(pcs[2], pcs[3], cache, "32")
-            fus[2] = early.get(("fus", 2))
+            fus[2] = sched.get(("fus", 2))
             f2o = feats_o[2]
             def chain2():
                 f = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
                 return self.mfa_projections(m + "multi_frame_up_2", f, sw(f), feats[2], fus[2], f2o, fus[2])
-            early.launch(("mfa_proj", 2), chain2, lane=2)
+            sched.run(("mfa_proj", 2), chain2)
             f_l3_2 = None
         else:
             f_l3_2 = self.conv1d_block(self.interp(pcs[2], pcs[3], new3, cache, "32"), m + "deconv3_2")
@@ -1173,11 +1097,11 @@ class MoCoPCI(nn.Module):
         ups = self.interp_flows(pcs[2], pcs[3], frame3s, cache, "32")
         C = feats[2].shape[-1]
         te = self.time_pair(B, C, dev)                                              # (2B,5,1,C)
-        fus[2] = early.get(("fus", 2))
+        fus[2] = sched.get(("fus", 2))
         self._mark("got early fus2/cos2")
-        frame2s, n1_2, n2_2 = self.multiframe_attention(m + "multi_frame_up_2", pcs[2], pcs_o[2], f_l3_2, None if side else sw(f_l3_2), feats[2],
-                                                        fus[2], feats_o[2], fus[2], ups, te, idx_c12=early.get(("cos", 2)),
-                                                        projections=("mfa_proj", 2) if side else None)  # (2B,3,N2,3)
+        frame2s, n1_2, n2_2 = self.multiframe_attention(m + "multi_frame_up_2", pcs[2], pcs_o[2], f_l3_2, None if proj else sw(f_l3_2), feats[2],
+                                                        fus[2], feats_o[2], fus[2], ups, te, idx_c12=sched.get(("cos", 2)),
+                                                        projections=("mfa_proj", 2) if proj else None)  # (2B,3,N2,3)
         # l2 -> l1 (mocopci.py:920-927): the forward branch upsamples (feat1_new_f -> pc1, feat2_new_f -> pc2),
         # the backward branch (feat1_new_b -> pc1, feat2_new_b -> pc2) where *_b come from the swapped call.
         def upsampled1():
@@ -1185,11 +1109,11 @@ class MoCoPCI(nn.Module):
             f2_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n2_2[B:], n1_2[B:]], 0), cache, "21"), m + "deconv2_1")
             # forward call gets (feat1_l2_1_f, feat2_l2_1_f); backward call gets (feat2_l2_1_b, feat1_l2_1_b)
             return torch.cat([f1_up[:B], f2_up[B:]], dim=0), torch.cat([f1_up[B:], f2_up[:B]], dim=0)
-        fus[1] = early.get(("fus", 1))
-        if side:
+        fus[1] = sched.get(("fus", 1))
+        if proj:
             self.interp_prepare(pcs[1], pcs[2], cache, "21")
             f1o = feats_o[1]
-            early.launch(("mfa_proj", 1), lambda: self.mfa_projections(m + "multi_frame_up_1", *upsampled1(), feats[1], fus[1], f1o, fus[1]), lane=1)
+            sched.run(("mfa_proj", 1), lambda: self.mfa_projections(m + "multi_frame_up_1", *upsampled1(), feats[1], fus[1], f1o, fus[1]))
             f_up_1 = f_up_1_o = None
         else:
             f_up_1, f_up_1_o = upsampled1()
@@ -1201,16 +1125,16 @@ class MoCoPCI(nn.Module):
         # (2B samples x 3 frames) only these 3B are read: [:B] frame 0, [:B] frame 1, [B:] frame 0.
         self._mark("level2 done, got early fus1")
         frame1s = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
-                                            feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=early.get(("cos", 1)),
-                                            projections=("mfa_proj", 1) if side else None)[0].contiguous()
+                                            feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=sched.get(("cos", 1)),
+                                            projections=("mfa_proj", 1) if proj else None)[0].contiguous()
         rep3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
         # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
         # (2B rows), its rows repeated for the 3B arrangement
-        if side0:
-            pc0, f0, i3r, w3r = early.get(("rep0",))
-        else:
+        if train:
             pc0, f0 = rep3(pcs[0]), rep3(feats[0])
-            i3, w3 = early.get("i3_01")
+            i3, w3 = sched.get("i3_01")
+        else:
+            pc0, f0, i3r, w3r = sched.get("rep0")
         if train:
             # all six upsampled level-1 flows (mocopci.py:1011-1019): up_f[i] = upsample(frame1s_f[:, i]) on frame 1's points,
             # up_b[i] = upsample(frame1s_b[:, 2 - i]) on frame 2's points
@@ -1221,69 +1145,47 @@ class MoCoPCI(nn.Module):
             up_flow = torch.cat([up_f[0], up_f[1], up_b[2]], dim=0)
         else:
             flow_src = frame1s                                                     # (3B,N1,3): the three flows read below
-            up_flow = ops.backend().interp3_apply(flow_src, *((i3r, w3r) if side0 else (rep3(i3), rep3(w3))))    # (3B,N,3)
+            up_flow = ops.backend().interp3_apply(flow_src, i3r, w3r)              # (3B,N,3)
         self._mark("level1 done")
         warped = pc0 + up_flow
-        # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022), then rlevel0
-        refine_feat = lambda: self.conv1d_block(f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev), m + "rlevel0")
-        if side0:  # read next by the refinement stage's PointConvD, after the sampling: beside the warped clouds' self search
-            f0.record_stream(self.side_stream(dev, 2))   # made on lane 1, read on lane 2
-            early.launch(("wf",), refine_feat, lane=2)
-        side = self.side_stream(dev, 5)  # NOT lane 0: the next batch's sampling pyramid is queued there (prefetch) and must not wait for this
-        if side is not None:
-            main = torch.cuda.current_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                down, sel = self.fps_gather(warped, 2048, return_idx=True)
-                done = torch.cuda.Event()
-                done.record(side)
-            down.record_stream(main)
-            sel.record_stream(main)
-        else:
-            down, sel = self.fps_gather(warped, 2048, return_idx=True)
-        wf = None if side0 else refine_feat()
+        # F.interpolate(size=32, mode="area") over the 3 flow components (mocopci.py:1021-1022), then rlevel0: read next by the
+        # refinement stage's PointConvD, after the sampling -- a node beside the warped clouds' self search
+        sched.run("wf", lambda: self.conv1d_block(f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev), m + "rlevel0"), reads=(f0,))
+        # the refinement stage's sampling: a 1.2-1.4 ms latency chain on 24 CUs
+        sched.run("refine_fps", lambda: self.fps_gather(warped, 2048, return_idx=True))
         idx_self = ops.backend().knn(warped, warped, 32)      # fusion's self search: independent of the refine branch
-        if side is not None and defer:
-            # The sampling (a 1.2-1.4 ms latency chain on 24 CUs) is on its way; whatever the caller enqueues on this stream before
-            # resuming runs beside it, so neither the wait for it nor the 4x speculative PointConvD below is paid.
+        be = ops.backend()
+        like = warped.shape[0] * warped.shape[1]   # kernels as for every candidate centre (what the speculative form computes): same bits
+        if defer and sched.lane("refine_fps") is not None:
+            # The sampling is on its way; whatever the caller enqueues on this stream before resuming runs beside it, so neither the
+            # wait for it nor the 4x speculative PointConvD below is paid.  The tensors the tail reads go to the caller (finish() may
+            # run the tail on another stream and must record them there).
             self._mark("refine FPS launched (tail deferred)")
-            issued = torch.cuda.current_stream(dev)
-            yield
-            main = torch.cuda.current_stream(dev)
-            if side0:
-                wf = early.get(("wf",))
-            if main != issued:  # finish(..., tail_stream=...): the tail runs on another stream than the part that produced these
-                for t_ in (warped, wf, idx_self, down, sel):
-                    t_.record_stream(main)
-            main.wait_event(done)
-            be = ops.backend()
-            early.launch("i3_refine", lambda: be.interp3_search(warped, down), lane=1)
-            if side0:  # the Point-Transformer's 16-NN search needs the sampled cloud only: beside PointConvD
-                down.record_stream(self.side_stream(dev, 2))
-                early.launch("knn_down", lambda: be.knn(down, down, 16, mode=ops.MCP_DIST_DIRECT), lane=2)
-            like = warped.shape[0] * warped.shape[1]   # kernels as for every candidate centre: what the speculative form below computes
-            dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel), like_rows=like)
-            shape = self.transformer_block(m + "shape1", dfeat, down, idx=early.get("knn_down") if side0 else None, like_rows=like)
-            upf = be.interp3_apply(shape, *early.get("i3_refine"))
-        elif side is not None:
-            if side0:
-                wf = early.get(("wf",))
+            yield (warped, idx_self)
+            down, sel = sched.get("refine_fps")
+            sched.run("i3_refine", lambda: be.interp3_search(warped, down))
+            # the Point-Transformer's 16-NN search needs the sampled cloud only: beside PointConvD
+            sched.run("knn_down", lambda: be.knn(down, down, 16, mode=ops.MCP_DIST_DIRECT), reads=(down,))
+            dfeat = self.pointconv(m + "level1", warped, down, sched.get("wf"), idx=self.sampled_neighbours(idx_self, sel), like_rows=like)
+            shape = self.transformer_block(m + "shape1", dfeat, down, idx=sched.get("knn_down"), like_rows=like)
+            upf = be.interp3_apply(shape, *sched.get("i3_refine"))
+        elif sched.lane("refine_fps") is not None:
             # same speculation as in the encoder: PointConvD of EVERY candidate centre and the Point-Transformer's four
             # per-point projections are computed while the sampling runs, the sampled rows are gathered afterwards
-            be = ops.backend()
             t = m + "shape1"
-            dfeat_all = self.pointconv(m + "level1", warped, warped, wf, idx=idx_self)
+            dfeat_all = self.pointconv(m + "level1", warped, warped, sched.get("wf"), idx=idx_self)
             qkv_all = self.qkv_projection(t, dfeat_all)                           # (3B,N,192)
             self._mark("refine speculation done (before FPS wait)")
-            main.wait_event(done)
+            down, sel = sched.get("refine_fps")
             # the 3-NN search of the upsampling below needs only (warped, down): it runs beside the Point-Transformer kernel
-            early.launch("i3_refine", lambda: be.interp3_search(warped, down), lane=1)
+            sched.run("i3_refine", lambda: be.interp3_search(warped, down))
             dfeat = be.group_rows(dfeat_all, sel)
             shape = self.transformer_block(t, dfeat, down, qkv=be.group_rows(qkv_all, sel))
-            upf = be.interp3_apply(shape, *early.get("i3_refine"))
+            upf = be.interp3_apply(shape, *sched.get("i3_refine"))
         else:
             # down = warped[sel]: its 32 nearest in warped are rows of the self search the fusion stage needs anyway
-            dfeat = self.pointconv(m + "level1", warped, down, wf, idx=self.sampled_neighbours(idx_self, sel))
+            down, sel = sched.get("refine_fps")
+            dfeat = self.pointconv(m + "level1", warped, down, sched.get("wf"), idx=self.sampled_neighbours(idx_self, sel))
             shape = self.transformer_block(m + "shape1", dfeat, down)
             upf = ops.backend().interp3(warped, down, shape)
         self._mark("ptblock + interp done")
@@ -1307,36 +1209,26 @@ class MoCoPCI(nn.Module):
     def prefetch(self, xyz1, xyz2, inputs_ready=None):
         """Issue NOW everything of an inference forward on (xyz1, xyz2) that depends on nothing but the inputs -- the channel-last
         layout, the encoder's furthest-point-sampling pyramid (a ~2.5 ms chain of latency-bound kernels on 16 CUs) and the level-0
-        self search -- on side streams, and return a handle for forward(..., prefetched=handle).  A serving loop calls it for batch
-        k+1 while batch k is still being computed (forward(then_prefetch=...) does so right after batch k's encoder is enqueued),
-        so the sampling chains run under batch k's decoder instead of stalling batch k+1's encoder.  inputs_ready: an event after
-        which the inputs are complete (a loader's copy-stream event); without it the work is ordered behind the current stream.
-        The inputs must stay unmodified until the consuming forward has run: an in-place refill of the same buffers (copy_, any
+        self search -- on side lanes (issue_inputs_only), and return a handle for forward(..., prefetched=handle).  A serving loop
+        calls it for batch k+1 while batch k is still being computed (forward(then_prefetch=...) does so right after batch k's encoder
+        is enqueued), so the sampling chains run under batch k's decoder instead of stalling batch k+1's encoder.  inputs_ready: an
+        event after which the inputs are complete (a loader's copy-stream event); without it the work is ordered behind the current
+        stream.  The inputs must stay unmodified until the consuming forward has run: an in-place refill of the same buffers (copy_, any
         in-place op) is detected through the tensors' version counters and the handle is then refused; writes through raw pointers
         are not seen.  Returns None on backends without streams."""
         dev = xyz1.device
-        side = self.side_stream(dev)
-        if side is None:
+        sched = Schedule(self, dev)
+        if sched.lane("xyz") is None:
             return None
         main = torch.cuda.current_stream(dev)
-        if inputs_ready is not None:
-            side.wait_event(inputs_ready)
-        else:
-            side.wait_stream(main)
+        if inputs_ready is None:   # no event: behind the caller's stream as it stands now
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(main)
         scope = {}
         with torch.no_grad(), ops.backend().cloud_scope(scope):
-            with torch.cuda.stream(side):
-                xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
-                laid_out = torch.cuda.Event()
-                laid_out.record(side)
-            xyz.record_stream(main)
-            pyramid = self.sample_pyramid(xyz, side)
-            # the level-0 self search (0.6 ms with its sorted cloud) on a lane of its own, so that it neither delays the sampling
-            # chain nor waits for it
-            self_search = self.early_self_search(xyz, laid_out, main)
+            self.issue_inputs_only(sched, lambda: torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous(), after=(inputs_ready,))
         return {"inputs": (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)), "versions": (xyz1._version, xyz2._version),
-                "stream": main.stream_id, "xyz": xyz, "laid_out": laid_out,
-                "pyramid": pyramid, "self_search": self_search, "scope": scope}
+                "stream": main.stream_id, "sched": sched, "scope": scope}
 
     def begin(self, xyz1, xyz2, prefetched=None, then_prefetch=None, inputs_ready=None):
         """First part of an inference forward, for a loop that keeps two batches in flight (software pipelining of consecutive
@@ -1356,22 +1248,22 @@ class MoCoPCI(nn.Module):
             h = self.prefetch(xyz1, xyz2, inputs_ready)
         scope = {} if h is None else h["scope"]
         with torch.no_grad(), be.cloud_scope(scope):
-            xyz, pyramid, self_search = self._consume_prefetched(h, xyz1, xyz2)
-            early = self._early = Early(self, xyz.device)
-            pcs, feats = self.run_encoder(xyz, early, pyramid=pyramid, self_search=self_search)
+            xyz, sched = self._consume_prefetched(h, xyz1, xyz2)
+            self._sched = sched
+            pcs, feats = self.run_encoder(xyz, sched)
             if then_prefetch is not None:
                 self._next = self.prefetch(*then_prefetch)
             gen = self._decoder(pcs, feats, B, defer=True)
             try:
-                next(gen)
+                reads = next(gen)
                 out = None
             except StopIteration as stop:  # backends without streams never defer
-                gen, out = None, stop.value
+                gen, out, reads = None, stop.value, ()
         ready = None
         if gen is not None:
             ready = torch.cuda.Event()
             ready.record()
-        return {"gen": gen, "scope": scope, "out": out, "ready": ready}
+        return {"gen": gen, "scope": scope, "out": out, "ready": ready, "sched": sched, "reads": reads}
 
     def finish(self, pending, tail_stream=None):
         """Second part of the forward begun with begin(): returns out_lst, 3 x (B,N,3).
@@ -1385,6 +1277,9 @@ class MoCoPCI(nn.Module):
         run_on = cur if tail_stream is None else tail_stream
         if run_on != cur:
             run_on.wait_event(pending["ready"])
+            for t in pending["reads"]:   # produced on the first part's stream, read by the tail on another one
+                t.record_stream(run_on)
+        self._sched = pending["sched"]   # (another batch's begin() has run in between)
         with torch.no_grad(), ops.backend().cloud_scope(pending["scope"]), torch.cuda.stream(run_on):
             try:
                 next(pending["gen"])
@@ -1403,9 +1298,9 @@ class MoCoPCI(nn.Module):
         return out
 
     def _consume_prefetched(self, h, xyz1, xyz2):
-        """(xyz, pyramid, self_search) of a forward: from the prefetch handle (the stream waits for its layout), or laid out here."""
+        """(xyz, schedule) of a forward: from the prefetch handle (the stream waits for its layout), or laid out here."""
         if h is None:
-            return torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous(), None, None
+            return torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous(), Schedule(self, xyz1.device)
         main = torch.cuda.current_stream(xyz1.device)
         if h["inputs"] != (xyz1.data_ptr(), xyz2.data_ptr(), tuple(xyz1.shape)) or h["stream"] != main.stream_id:
             raise RuntimeError("prefetched handle belongs to other inputs or another stream")
@@ -1413,8 +1308,7 @@ class MoCoPCI(nn.Module):
             # a loader refilled the buffers in place (copy_ / in-place ops) after prefetch() laid them out: the handle holds the OLD
             # contents.  (Writes through raw pointers are invisible to the version counters and remain the caller's responsibility.)
             raise RuntimeError("the inputs were modified in place after prefetch(): prefetch them again")
-        main.wait_event(h["laid_out"])
-        return h["xyz"], h["pyramid"], h["self_search"]
+        return h["sched"].get("xyz"), h["sched"]
 
     def take_prefetched(self):
         """The handle forward(then_prefetch=...) produced (None if it did not); hands it over once."""
@@ -1445,9 +1339,8 @@ class MoCoPCI(nn.Module):
             if h is None and inputs_ready is not None:
                 h = self.prefetch(xyz1, xyz2, inputs_ready)
             with torch.no_grad(), ops.backend().cloud_scope(None if h is None else h["scope"]):
-                xyz, pyramid, self_search = self._consume_prefetched(h, xyz1, xyz2)
-                self._early = Early(self, xyz.device)
-                pcs, feats = self.run_encoder(xyz, self._early, pyramid=pyramid, self_search=self_search)
+                xyz, self._sched = self._consume_prefetched(h, xyz1, xyz2)
+                pcs, feats = self.run_encoder(xyz, self._sched)
                 if then_prefetch is not None:
                     self._next = self.prefetch(*then_prefetch)
                 return self.run_decoder(pcs, feats, B)
@@ -1456,8 +1349,8 @@ class MoCoPCI(nn.Module):
         self._mode = (float(self.drop_rate), float(self.attn_drop_rate), float(self.drop_path_rate)) if self.training else None
         try:
             with torch.enable_grad(), ops.backend().cloud_scope():
-                self._early = Early(self, xyz.device)
-                pcs, feats = self.run_encoder(xyz, self._early)
+                self._sched = Schedule(self, xyz.device)
+                pcs, feats = self.run_encoder(xyz, self._sched)
                 flows_f, flows_b, out_lst = self.run_decoder(pcs, feats, B, train=True)
         finally:
             self._live = None

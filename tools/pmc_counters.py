@@ -26,7 +26,7 @@ FAMILIES = {  # name -> kernel-name substrings
     "knn": ("knn_walk_kernel", "knn_pruned_kernel", "knn_queue_kernel", "knn_small_kernel"),
     "knn_pruned": ("knn_walk_kernel", "knn_pruned_kernel"),
     "build_cloud": ("build_cloud_kernel",),
-    "knn_cosine": ("knn_cosine_kernel",),
+    "knn_cosine": ("knn_cosine_kernel", "knn_cosine_split_kernel"),
     "fusion": ("fusion_kernel", "fusion_split_kernel"),
     "cross": ("cross_kernel",),
     "pointconv": ("pointconv_agg_kernel", "pointconv_agg_lowlevel_kernel", "pointconv_linear_kernel"),

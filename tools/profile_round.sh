@@ -7,16 +7,16 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- $B > "$out/trace_bench.json" 2> "$out/trace.err"
+B="python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-}"
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- $B > "$out/trace_bench.json" 2> "$out/trace.err"
 db=$(find "$out/trace" -name '*.db' | head -1)
 python3 tools/rocpd_stats.py "$db" "$out/kernel_stats.csv" "$out/step_by_queue.txt" > /dev/null
 echo "trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o f -- $B > "$out/pmc_fetch.log" 2>&1
+timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o f -- $B > "$out/pmc_fetch.log" 2>&1
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o w -- $B > "$out/pmc_write.log" 2>&1
+timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o w -- $B > "$out/pmc_write.log" 2>&1
 echo "write done"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+timeout -k 5 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
     --output-format csv -d "$out/pmc_sq" -o s -- $B > "$out/pmc_sq.log" 2>&1
 echo "sq done"
 python3 -c "import json, bench; json.dump({'csrc_sha256': bench.kernel_sources_digest()}, open('$out/pmc_sources.json', 'w'))"
