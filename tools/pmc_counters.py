@@ -37,6 +37,10 @@ FAMILIES = {  # name -> kernel-name substrings
     "mlp": ("mlp2_kernel",),
     "linear": ("linear_kernel",),
     "group_rows": ("group_rows_kernel",),
+    "ball_query": ("ball_query_kernel", "query_and_group_kernel"),
+    "three_nn": ("three_nn_kernel",),
+    "fps_tiled": ("fps_tiled_kernel",),
+    "knn_walk": ("knn_walk_kernel",),
     "interp3": ("interp3_",),
     "dense": ("dense_",),
     "gemm_library": ("Cijk_",),
