@@ -167,3 +167,17 @@ def test_bench_two_ranks_rehearsal_as_child_process():
     assert res["n_gpus"] == 2 and res["n_ranks_seen"] == 2
     assert res["config"]["global_batch"] == 16 and res["scaling"] == "weak"
     assert res["value"] > 0 and res["metric"] == "interpolated frames/sec"
+
+
+def test_bench_config5_line_as_child_process():
+    """`bench.py --config c5` (BASELINE configs[4]: FPS 65536 -> 2048 + 32-NN, kernels only) prints one JSON line with the roofline objects
+    of its three kernels; run as the driver would, in a fresh process."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c5", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["unit"] == "clouds/s" and line["value"] > 0 and line["config"]["bench_config"] == "c5"
+    kernels = [line["roofline"]] + line["roofline_others"]
+    assert len(kernels) == 4 and all(k["avg_launch_us"] > 0 and 0 < k["frac"] for k in kernels)

@@ -390,6 +390,28 @@ def test_knn_pruned_equals_bruteforce_and_oracle(q, n, k, mode, b):
         assert torch.equal(gi_.cpu(), wi) and torch.equal(gd.cpu(), wd)
 
 
+@pytest.mark.parametrize("n,q,k,mode", [(10, 40, 32, 0), (31, 100, 32, 1), (33, 64, 32, 0), (70, 17, 32, 0), (200, 300, 32, 1), (4096, 4096, 20, 0),
+                                        (4096, 4096, 24, 1), (2500, 1100, 17, 0), (5000, 4096, 31, 0)])
+def test_knn_walk_kernel_edges_through_the_c_abi(n, q, k, mode):
+    """The K = 32 walk kernel straight through mcp_build_cloud + mcp_knn_pruned at the shapes the Python layer never sends it: fewer
+    references than list entries (the missing ranks repeat the last valid one, as the exhaustive kernel does), a partial last tile,
+    query counts that leave lanes dead, and row widths that are not whole 16-byte pieces (k = 17, 20, 24, 31)."""
+    be = ops.backend()
+    ref = cloud(401 + n, 2, n).to(DEV)
+    query = cloud(402 + q, 2, q).to(DEV)
+    B = 2
+    rs, rperm, rboxes = be._build_cloud(ref)
+    qs, qperm, _ = be._build_cloud(query)
+    idx = torch.empty((B, q, k), dtype=torch.int32, device=DEV)
+    dist = torch.empty((B, q, k), dtype=torch.float32, device=DEV)
+    ops._call("mcp_knn_pruned", query, B, q, n, k, mode, _lib.fptr(qs), _lib.iptr(qperm), _lib.fptr(rs), _lib.iptr(rperm), _lib.fptr(rboxes),
+              _lib.iptr(idx), _lib.fptr(dist))
+    bi, bd = be.knn_bruteforce(query, ref, k, mode=mode, return_dist=True)
+    assert torch.equal(idx, bi) and torch.equal(dist, bd)
+    wi, wd = orc.knn(query.cpu(), ref.cpu(), k, mode=mode, return_dist=True)
+    assert torch.equal(idx.cpu(), wi) and torch.equal(dist.cpu(), wd)
+
+
 def test_interp3_search_pruned_route_matches_oracle():
     # dense 8192 / sparse 2048: the 3-NN search takes the pruned kernel (K <= 4 list), weights come from mcp_interp3_weights
     be = ops.backend()
