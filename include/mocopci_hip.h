@@ -216,6 +216,24 @@ int mcp_interp3_apply_grad(int b, int n, int s, int c, const float *grad_out, co
 int mcp_fusion(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1,
                const float *w2, const float *b2, const float *w3, const float *b3, float *out, mcp_stream_t stream);
 
+/* Backward of mcp_fusion (the reference differentiates mocopci.py:803-819 with autograd over the materialised (B,128,N,64)
+ * activations; its only hand-written backward pieces are the atomicAdd scatters of group_points_gpu.cu:8-44).  Same arguments as
+ * mcp_fusion, plus grad_out (B,N,3) = dL/dout.  Writes
+ *   grad_p1 (B,N,3)       dL/dp1;
+ *   grad_nb (B,N,64,3)    dL/d(p2[idx]) per gathered neighbour, in the order of the neighbour list(s) -- the caller scatters it into
+ *                         dL/dp2 with mcp_group_rows_grad_sorted (deterministic) or any scatter-add of its own;
+ *   grad_weights          mcp_fusion_grad_floats() = 12800 floats: dW1 (64,4) | db1 (64) | dW2 (64,64) | db2 (64) | dW3 (128,64) | db3 (128),
+ *                         with respect to the (BatchNorm-folded) w, b the caller passed.
+ * The layer is re-evaluated inside the kernel (nothing of size B x N x 64 x C is read or written except grad_nb); weight
+ * gradients are summed per wave, per workgroup and over workgroups in fixed orders: results repeat bit for bit.
+ * workspace: mcp_fusion_grad_workspace_bytes(b, n) bytes of device memory (the workgroups' partial weight gradients); w3 16-byte
+ * aligned.  ReLU and the channel max take torch's subgradients (0 at 0; one arg-max channel), |r| has gradient 0 at r = 0. */
+int mcp_fusion_grad_floats(void);
+size_t mcp_fusion_grad_workspace_bytes(int b, int n);
+int mcp_fusion_grad(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1,
+                    const float *w2, const float *b2, const float *w3, const float *b3, const float *grad_out, float *grad_p1, float *grad_nb,
+                    float *grad_weights, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+
 /* Cost-volume cross() after its neighbour searches (pointconv_util.py:750-781, :894-922, :1126-1161):
  * xyz1 (B,N1,3), xyz2 (B,N2,3), points1 (B,N1,D), points2 (B,N2,D) channel-last (16-byte aligned),
  * idx (B,N1,32) int32 into set 2 (16 feature-cosine + 16 xyz neighbours) -> out (B,N1,D) = max over the 32

@@ -49,6 +49,9 @@ SIGNATURES = {
     "mcp_group_rows_grad_sorted": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_group_rows_add_leaky": [_i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     "mcp_fusion": [_i, _i, _i] + [_p] * 12,
+    "mcp_fusion_grad_floats": [],
+    "mcp_fusion_grad_workspace_bytes": [_i, _i],
+    "mcp_fusion_grad": [_i, _i, _i] + [_p] * 15 + [ctypes.c_size_t, _p],
     "mcp_cross_packed_floats": [_i],
     "mcp_cross_pack": [_i, _p, _p, _p, _p, _p, _p],
     "mcp_cross_volume": [_i] * 5 + [_p] * 7 + [_i, _p, _p, _p],
@@ -75,7 +78,7 @@ SIGNATURES = {
     "mcp_prof_enable": [_i],
     "mcp_prof_collect": [_i, _p, _p],
 }
-_RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": ctypes.c_size_t}
+_RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": ctypes.c_size_t, "mcp_fusion_grad_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

@@ -70,18 +70,57 @@ class _GroupRowsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        """Deterministic segmented reduction: stable sort of the gather positions by destination row, in-order sums per row."""
         (idx,) = ctx.saved_tensors
-        B, C = grad_out.shape[0], grad_out.shape[-1]
-        T, N = idx[0].numel(), ctx.n
+        return _group_rows_grad(grad_out, idx, ctx.n), None
+
+
+def _group_rows_grad(grad_out, idx, n):
+    """Scatter-add of gathered rows' gradients (B,...,C) back to (B,n,C) as a deterministic segmented reduction: stable sort of the
+    gather positions by destination row, in-order sums per row."""
+    B, C = grad_out.shape[0], grad_out.shape[-1]
+    T = idx[0].numel()
+    grad_out = grad_out.contiguous()
+    keys, order = torch.sort(idx.reshape(B, T), dim=1, stable=True)
+    bounds = torch.arange(n + 1, device=idx.device, dtype=keys.dtype).expand(B, n + 1).contiguous()
+    seg = torch.searchsorted(keys.contiguous(), bounds).int()
+    grad_rows = torch.empty((B, n, C), dtype=torch.float32, device=grad_out.device)
+    _call("mcp_group_rows_grad_sorted", grad_out, B, n, C, T, _lib.fptr(grad_out), _lib.iptr(order.int().contiguous()), _lib.iptr(seg.contiguous()),
+          _lib.fptr(grad_rows))
+    return grad_rows
+
+
+class _FusionFn(torch.autograd.Function):
+    """mcp_fusion with its hand-written backward (mcp_fusion_grad): the layer is re-evaluated inside the backward kernel, the
+    neighbour gradients go through the deterministic segmented scatter, weight gradients are fixed-order sums."""
+
+    @staticmethod
+    def forward(ctx, be, ia, ib, p1, p2, w1, b1, w2, b2, w3, b3):
+        args = [t.detach().contiguous() for t in (p1, p2, w1, b1, w2, b2, w3, b3)]
+        ctx.save_for_backward(ia, ib, *args)
+        return be._fusion_mlp(args[0], args[1], ia if ib is None else (ia, ib), *args[2:])
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ia, ib, p1, p2, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
+        B, N, _ = p1.shape
+        lib = _lib.load()
         grad_out = grad_out.contiguous()
-        keys, order = torch.sort(idx.reshape(B, T), dim=1, stable=True)
-        bounds = torch.arange(N + 1, device=idx.device, dtype=keys.dtype).expand(B, N + 1).contiguous()
-        seg = torch.searchsorted(keys.contiguous(), bounds).int()
-        grad = torch.empty((B, N, C), dtype=torch.float32, device=grad_out.device)
-        _call("mcp_group_rows_grad_sorted", grad_out, B, N, C, T, _lib.fptr(grad_out), _lib.iptr(order.int().contiguous()), _lib.iptr(seg.contiguous()),
-              _lib.fptr(grad))
-        return grad, None
+        d_p1 = torch.empty_like(p1)
+        d_nb = torch.empty((B, N, 64, 3), dtype=torch.float32, device=p1.device)
+        d_w = torch.empty((lib.mcp_fusion_grad_floats(),), dtype=torch.float32, device=p1.device)
+        need = lib.mcp_fusion_grad_workspace_bytes(B, N)
+        ws = torch.empty((need,), dtype=torch.uint8, device=p1.device)
+        _call("mcp_fusion_grad", p1, B, N, 64, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib), _lib.fptr(w1),
+              _lib.fptr(b1), _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(w3), _lib.fptr(b3), _lib.fptr(grad_out), _lib.fptr(d_p1), _lib.fptr(d_nb),
+              _lib.fptr(d_w), ws.data_ptr(), need)
+        d_p2 = None
+        if ctx.needs_input_grad[4]:
+            d_p2 = _group_rows_grad(d_nb, ia if ib is None else torch.cat((ia, ib), dim=-1), p2.shape[1])
+        pieces, at = [], 0
+        for t in (w1, b1, w2, b2, w3, b3):
+            pieces.append(d_w[at:at + t.numel()].view(t.shape))
+            at += t.numel()
+        return (None, None, None, d_p1, d_p2, *pieces)
 
 
 class HipBackend:
@@ -281,7 +320,10 @@ class HipBackend:
 
     def fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
         """fusion after the neighbour searches (mocopci.py:803-819), BN folded into (w,b): -> (B,N,3).  Differentiable."""
-        return grad.run(self._fusion_mlp, lambda *a: grad.fusion_twin(self.group_rows, *a), p1, p2, idx, w1, b1, w2, b2, w3, b3)
+        if not grad.wants_grad(p1, p2, w1, b1, w2, b2, w3, b3):
+            return self._fusion_mlp(p1, p2, idx, w1, b1, w2, b2, w3, b3)
+        ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
+        return _FusionFn.apply(self, ia.contiguous(), None if ib is None else ib.contiguous(), p1, p2, w1, b1, w2, b2, w3, b3)
 
     def _fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
         p1, p2, w1, b1, w2, b2, w3, b3 = (t.contiguous() for t in (p1, p2, w1, b1, w2, b2, w3, b3))

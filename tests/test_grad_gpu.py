@@ -94,6 +94,35 @@ def test_fusion_gradients():
                   names=["p1", "p2", "w1", "b1", "w2", "b2", "w3", "b3"], rtol=5e-4)
 
 
+def test_fusion_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bit():
+    """mcp_fusion_grad against autograd over the unfused layer (grad.fusion_twin) on the device, with the neighbour list given as the
+    two searches' halves, a point count that leaves the last workgroup ragged, and duplicate neighbours (a point is its own
+    neighbour: r = 0, where |r| takes the zero subgradient); two runs give identical bits (fixed-order weight-gradient sums)."""
+    from mocopci_amd import grad
+    be = ops.backend()
+    p1 = cloud(130, 3, 1501).to(DEV)
+    p2 = p1.clone()
+    p2[1:] += rnd(131, 2, 1501, 3, scale=0.2).to(DEV)      # batch element 0: p2 == p1, so every point's first self-neighbour has r = 0
+    halves = (be.knn(p1, p1, 32), be.knn(p1, p2, 32))
+    ws = [rnd(132, 64, 4, scale=0.5), rnd(133, 64, scale=0.1), rnd(134, 64, 64, scale=0.125), rnd(135, 64, scale=0.1), rnd(136, 128, 64, scale=0.125),
+          rnd(137, 128, scale=0.1)]
+    g = rnd(138, 3, 1501, 3).to(DEV)
+    names = ["p1", "p2", "w1", "b1", "w2", "b2", "w3", "b3"]
+
+    def grads(fn):
+        leaves = [t.detach().clone().to(DEV).requires_grad_(True) for t in (p1, p2, *ws)]
+        return torch.autograd.grad(fn(*leaves), leaves, g)
+    hip = grads(lambda a, b, *w: be.fusion_mlp(a, b, halves, *w))
+    again = grads(lambda a, b, *w: be.fusion_mlp(a, b, halves, *w))
+    want = grads(lambda a, b, *w: grad.fusion_twin(be.group_rows, a, b, halves, *w))
+    for name, a, a2, b in zip(names, hip, again, want):
+        assert torch.equal(a, a2), name
+        assert torch.isfinite(a).all(), name
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        assert err <= 2e-4 * scale + 2e-5, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
+
+
 def test_ptblock_gradients():
     n = 333
     xyz = cloud(40, 2, n)
