@@ -252,6 +252,25 @@ int mcp_cross_pack(int d, const float *wpos, const float *bpos, const float *wml
 int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1,
                      const float *points2, const int *idx, const int *idx2, const int *bmap, int shared, const float *packed, float *out, mcp_stream_t stream);
 
+/* Backward of mcp_cross_volume for one cross layer given by its own weights (the reference differentiates pointconv_util.py:765-781
+ * with autograd over three materialised (B,D,32,N1) tensors; its hand-written backward pieces are the atomicAdd scatters of
+ * group_points_gpu.cu:8-44).  xyz1, xyz2, points1, points2, idx / idx2 as mcp_cross_volume (no batch map); wpos (D,3), bpos (D),
+ * wmlp (D,D), bmlp (D) row-major; grad_out (B,N1,D) = dL/dout.  Writes
+ *   grad_xyz1 (B,N1,3), grad_points1 (B,N1,D);
+ *   grad_dir (B,N1,32,3) and grad_rows (B,N1,32,D): dL/d(xyz2[idx]) and dL/d(points2[idx]) per gathered neighbour, in the order of
+ *       the neighbour list(s) -- the caller scatters them with mcp_group_rows_grad_sorted (deterministic);
+ *   grad_weights: mcp_cross_grad_floats(d) floats = dWpos (D,3) | dbpos (D) | dWmlp (D,D) | dbmlp (D).
+ * The layer is re-evaluated in the kernel; the arg-max neighbour of a channel is the lowest list position among equal maxima;
+ * all sums run in fixed orders (results repeat bit for bit).  workspace: mcp_cross_grad_workspace_bytes(b, n1, d) bytes.
+ * D = 64 (the level-1 cost volumes, 70 % of the layer's backward time at the training shape); other D: MCP_ERR_UNSUPPORTED,
+ * mcp_cross_grad_floats returns 0. */
+int mcp_cross_grad_floats(int d);
+size_t mcp_cross_grad_workspace_bytes(int b, int n1, int d);
+int mcp_cross_grad(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
+                   const int *idx, const int *idx2, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp,
+                   const float *grad_out, float *grad_xyz1, float *grad_dir, float *grad_points1, float *grad_rows, float *grad_weights,
+                   void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+
 /* PointConv / PointConvD up to the final Linear (mocopci.py:1218-1266, :1289-1300, :1330-1335):
  * s_xyz (B,N,3), new_xyz (B,S,3) centres, s_points (B,N,D) channel-last, idx (B,S,32) int32 into the
  * N source points; WeightNet Conv2d 3->8->8->8 + ReLU as w0 (8,3), w1 (8,8), w2 (8,8) and biases.

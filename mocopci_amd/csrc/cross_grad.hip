@@ -1,0 +1,409 @@
+// cross_grad.hip -- backward of the fused cost volume (mcp_cross_volume; CrossLayerLightFeatCosine.cross, pointconv_util.py:750-781,
+// BidirectionalLayerFeatCosine.cross :894-922, FlowEmbeddingLayer.forward :1126-1161) for gfx950.  The reference differentiates
+//     u = points2[idx] + points1 + Conv2d_{3->D}(xyz2[idx] - xyz1),  x = LeakyReLU(u),  z = Conv2d_{D->D}(x),  out = max_j LeakyReLU(z_j)
+// with autograd over three materialised (B,D,32,N1) tensors.  Here one wave owns one point at a time, re-evaluates x and z in the
+// forward's MFMA layout (neighbours on the MFMA column, lane & 31) and back-propagates inside the kernel:
+//   * arg-max neighbour of every channel: an all-reduce max over the 32 lanes of a lane half on order-preserving integer keys, ties
+//     resolved to the lowest neighbour position with the comparison's own lane mask (the two 16-neighbour lists overlap, so exact
+//     ties are common) -- dz is non-zero only there: dz_j[c] = g[c] LeakyReLU'(z_j[c]) [j = j*(c)];
+//   * dx = Wmlp^T dz on the split-bf16 MFMA path, the gradient tile chained as B operand exactly like the forward's activations;
+//     du = dx LeakyReLU'(u);  d_rows (B,N1,32,D) = du and d_dir (B,N1,32,3) = Wpos^T du leave for the caller's deterministic
+//     segmented scatters into dL/dpoints2 and dL/dxyz2;  dL/dpoints1 = sum_j du_j, dL/dxyz1 = -sum_j d_dir_j;
+//   * weight gradients contract over the NEIGHBOUR axis, so dz, x and du pass once through a per-wave LDS tile (written in
+//     accumulator layout, read back with 8 consecutive neighbours per lane): dWmlp += dz . x^T on the MFMA (both operands split
+//     three ways), dbmlp, dWpos, dbpos and dL/dpoints1 as in-lane sums with lane = channel.
+//   Weight gradients accumulate in registers over a wave's points; waves are added in wave order through LDS, workgroups in
+//   workgroup order by a second kernel: every sum has a fixed order, the gradients repeat bit for bit.
+#include "common.h"
+#include "mfma_split.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KNB = 32;
+constexpr float SLOPE = 0.1f;  // pointconv_util.py:10
+constexpr int TS = 36;         // row stride (floats) of the transposition tile
+
+__device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ float leaky(float v) { return mcp_max_raw(v, v * SLOPE); }  // as the forward (cross.hip)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t max_dpp(uint32_t v) {
+    const uint32_t o = mcp_dpp<CTRL>(v);
+    return v > o ? v : o;
+}
+// maximum over the 32 lanes that share lane >> 5, in every lane
+__device__ __forceinline__ uint32_t half_max_u32(uint32_t v) {
+    v = max_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = max_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = max_dpp<0x141>(v);  // row_half_mirror
+    v = max_dpp<0x140>(v);  // row_mirror
+    const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // odd rows of one copy <-> even rows of the other
+    return sw[0] > sw[1] ? sw[0] : sw[1];
+}
+
+template <int D>
+struct GradShape {
+    static constexpr int T = D / 32;
+    static constexpr int WAVES = 4;
+    // weight-gradient vector (floats): dWpos (D,3) | dbpos (D) | dWmlp (D,D) | dbmlp (D)
+    static constexpr int G_WP = 0, G_BP = 3 * D, G_WM = 4 * D, G_BM = 4 * D + D * D, G_FLOATS = G_BM + D;
+    // LDS, floats: pos image [t][s][lane] | bmlp [t][h][r] | Wpos rows [t][h][r][4]
+    static constexpr int L_POS = 0, L_B = T * 2 * 64, L_WPR = L_B + T * 32, L_F32 = L_WPR + T * 32 * 4;
+    static constexpr int W_U4 = T * (2 * T) * 3 * 64;  // uint4 per split image (Wmlp, Wmlp^T)
+    // per wave (floats): tile [D][TS] | directions [32][4]
+    static constexpr int S_T = 0, S_DIR = D * TS, S_FLOATS = S_DIR + 128;
+    static constexpr size_t LDS_BYTES = (size_t)L_F32 * 4 + (size_t)2 * W_U4 * 16 + (size_t)WAVES * S_FLOATS * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert((size_t)G_FLOATS * 4 <= (size_t)L_F32 * 4 + (size_t)2 * W_U4 * 16, "the reduction buffer overlays the weight images");
+};
+
+__device__ __forceinline__ void split_weights_transposed(uint4 *dst, const float *__restrict__ w, int m_total, int k_total, int first, int stride) {
+    const int ksteps = k_total / 16, out_tiles = m_total / 32;  // image of A[m][k] = w[k * m_total + m]
+    for (int e = first; e < out_tiles * ksteps * 64; e += stride) {
+        const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w[(size_t)(32 * (s >> 1) + mcp_chan_of(8 * (s & 1) + i, lane >> 5)) * m_total + 32 * t + (lane & 31)];
+        const McpSplit3 sp = mcp_split8(v);
+        uint4 *o = dst + (size_t)(t * ksteps + s) * 3 * 64 + lane;
+        o[0] = sp.p1;
+        o[64] = sp.p2;
+        o[128] = sp.p3;
+    }
+}
+
+__device__ __forceinline__ void read8(const float *row, float *v) {
+    const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <int T>
+__device__ __forceinline__ void write_tiles(float *tb, const f32x16 *v, int col, int h) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[(32 * t + chan_of(r, h)) * TS + col] = v[t][r];
+}
+__device__ __forceinline__ f32x16 mfma_split6(const McpSplit3 &a, const McpSplit3 &b, f32x16 acc) {
+    acc = mcp_mfma_bf16(a.p3, b.p1, acc);
+    acc = mcp_mfma_bf16(a.p1, b.p3, acc);
+    acc = mcp_mfma_bf16(a.p2, b.p2, acc);
+    acc = mcp_mfma_bf16(a.p2, b.p1, acc);
+    acc = mcp_mfma_bf16(a.p1, b.p2, acc);
+    acc = mcp_mfma_bf16(a.p1, b.p1, acc);
+    return acc;
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel(
+    long long total, int n1, int n2, const float *__restrict__ xyz1, const float *__restrict__ xyz2, const float *__restrict__ points1,
+    const float *__restrict__ points2, const int *__restrict__ idx, const int *__restrict__ idx2, const float *__restrict__ wpos,
+    const float *__restrict__ bpos, const float *__restrict__ wmlp, const float *__restrict__ bmlp, const float *__restrict__ gout,
+    float *__restrict__ d_xyz1, float *__restrict__ d_dir, float *__restrict__ d_points1, float *__restrict__ d_rows, float *__restrict__ partial) {
+    using S = GradShape<D>;
+    constexpr int T = S::T, WAVES = S::WAVES;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4 *wms = reinterpret_cast<uint4 *>(lds + S::L_F32);
+    uint4 *wmts = wms + S::W_U4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    float *scr = reinterpret_cast<float *>(wmts + S::W_U4) + wave * S::S_FLOATS;
+    float *tb = scr + S::S_T;
+    float4 *dirb = reinterpret_cast<float4 *>(scr + S::S_DIR);
+
+    for (int e = tid; e < T * 128; e += 64 * WAVES) {  // [t][s][lane]: columns (dx,dy | dz,1) of [Wpos | bpos], as cross_pack_kernel
+        const int l = e & 63, s = (e >> 6) & 1, t = e >> 7;
+        const int row = 32 * t + (l & 31), c = 2 * s + (l >> 5);
+        lds[S::L_POS + e] = c < 3 ? wpos[row * 3 + c] : bpos[row];
+        const int k = e & 3, r = (e >> 2) & 15, hh = (e >> 6) & 1;  // Wpos rows in accumulator order, for d_dir = Wpos^T du
+        lds[S::L_WPR + e] = k < 3 ? wpos[(32 * t + chan_of(r, hh)) * 3 + k] : 0.f;
+    }
+    for (int e = tid; e < T * 32; e += 64 * WAVES) {
+        const int r = e & 15, hh = (e >> 4) & 1, t = e >> 5;
+        lds[S::L_B + e] = bmlp[32 * t + chan_of(r, hh)];
+    }
+    mcp_split_weights(wms, wmlp, D, T, tid, 64 * WAVES);
+    split_weights_transposed(wmts, wmlp, D, D, tid, 64 * WAVES);
+    __syncthreads();
+
+    f32x16 dWa[T][T];  // dWmlp tiles: row = 32 mt + chan_of(r, h), column = 32 nt + col
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dWa[a][b][r] = 0.f;
+    float dbm[T], dbp[T], dWp[T][3];  // lane = channel 32 mt + col; the two lane halves hold the two 8-neighbour groups
+#pragma unroll
+    for (int t = 0; t < T; ++t) { dbm[t] = 0.f; dbp[t] = 0.f; dWp[t][0] = 0.f; dWp[t][1] = 0.f; dWp[t][2] = 0.f; }
+    const uint32_t lower_lanes = (1u << col) - 1u;
+
+    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+        const long long bb = mcp_div(p, n1, mcp_fits32(total));
+        const int id = idx2 ? (col >= 16 ? idx2[p * 16 + col - 16] : idx[p * 16 + col]) : idx[p * KNB + col];
+        const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
+        const float dx = q2[0] - xyz1[p * 3 + 0], dy = q2[1] - xyz1[p * 3 + 1], dzc = q2[2] - xyz1[p * 3 + 2];
+        const float in0 = h ? dy : dx, in1 = h ? 1.0f : dzc;
+        const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)bb * n2 + id) * D);
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + p * D);
+        const float4 *grow = reinterpret_cast<const float4 *>(gout + p * D);
+        // ---- the forward again: x = LeakyReLU(points2[idx] + points1 + pos), z = Wmlp x + b ----
+        f32x16 x[T];
+        {
+            McpSplit3 xs[2 * T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x16 acc;
+                float4 rg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 a = row1[(32 * t + 8 * g + 4 * h) >> 2];
+                    rg[g] = row2[(32 * t + 8 * g + 4 * h) >> 2];
+                    acc[4 * g + 0] = a.x; acc[4 * g + 1] = a.y; acc[4 * g + 2] = a.z; acc[4 * g + 3] = a.w;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[S::L_POS + (t * 2 + 0) * 64 + lane], in0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[S::L_POS + (t * 2 + 1) * 64 + lane], in1, acc, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[4 * g + 0] = leaky(acc[4 * g + 0] + rg[g].x);
+                    acc[4 * g + 1] = leaky(acc[4 * g + 1] + rg[g].y);
+                    acc[4 * g + 2] = leaky(acc[4 * g + 2] + rg[g].z);
+                    acc[4 * g + 3] = leaky(acc[4 * g + 3] + rg[g].w);
+                }
+                x[t] = acc;
+                xs[2 * t + 0] = mcp_split_kstep(acc, 0);
+                xs[2 * t + 1] = mcp_split_kstep(acc, 1);
+            }
+            // z tile by tile; dz_j[c] = g[c] LeakyReLU'(z_j[c]) at the arg-max neighbour (lowest position among equals), 0 elsewhere
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = lds[S::L_B + (t * 2 + h) * 16 + r];
+                acc = mcp_tile_split<2 * T>(wms + (size_t)t * (2 * T) * 3 * 64 + lane, xs, acc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 gv = grow[(32 * t + 8 * g + 4 * h) >> 2];
+                    const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        const float zv = acc[r];
+                        const uint32_t key = mcp_ord(zv);
+                        const bool top = key == half_max_u32(key);
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(top);
+                        const uint32_t mine = h ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+                        const bool winner = top && (mine & lower_lanes) == 0u;
+                        // written into the transposition tile right away (row = channel, column = neighbour): the A operand of dWmlp
+                        tb[(32 * t + chan_of(r, h)) * TS + col] = winner ? (zv > 0.f ? gq[i] : SLOPE * gq[i]) : 0.f;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- dWmlp += dz . x^T, dbmlp ----
+        McpSplit3 as[T][2];
+#pragma unroll
+        for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+                read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                dbm[mt] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                as[mt][ks] = mcp_split8(v);
+            }
+        // dz back in accumulator layout (the B operand of dx = Wmlp^T dz)
+        McpSplit3 zs[2 * T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x16 dzt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dzt[r] = tb[(32 * t + chan_of(r, h)) * TS + col];
+            zs[2 * t + 0] = mcp_split_kstep(dzt, 0);
+            zs[2 * t + 1] = mcp_split_kstep(dzt, 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        write_tiles<T>(tb, x, col, h);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nt = 0; nt < T; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+                read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
+                const McpSplit3 bs = mcp_split8(v);
+#pragma unroll
+                for (int mt = 0; mt < T; ++mt) dWa[mt][nt] = mfma_split6(as[mt][ks], bs, dWa[mt][nt]);
+            }
+        // ---- du = LeakyReLU'(u) . Wmlp^T dz ----
+        f32x16 du[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            acc = mcp_tile_split<2 * T>(wmts + (size_t)t * (2 * T) * 3 * 64 + lane, zs, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) du[t][r] = x[t][r] > 0.f ? acc[r] : SLOPE * acc[r];  // x = LeakyReLU(u) has u's sign
+        }
+        // ---- per-neighbour outputs: d_rows = du, d_dir = Wpos^T du ----
+        {
+            float4 *orow = reinterpret_cast<float4 *>(d_rows + (p * KNB + col) * D);
+            float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    orow[(32 * t + 8 * g + 4 * h) >> 2] = make_float4(du[t][4 * g + 0], du[t][4 * g + 1], du[t][4 * g + 2], du[t][4 * g + 3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 w = reinterpret_cast<const float4 *>(lds + S::L_WPR)[(t * 2 + h) * 16 + 4 * g + i];
+                        ax = __builtin_fmaf(w.x, du[t][4 * g + i], ax);
+                        ay = __builtin_fmaf(w.y, du[t][4 * g + i], ay);
+                        az = __builtin_fmaf(w.z, du[t][4 * g + i], az);
+                    }
+                }
+            ax += __shfl_xor(ax, 32);
+            ay += __shfl_xor(ay, 32);
+            az += __shfl_xor(az, 32);
+            if (h == 0) {
+                float *o = d_dir + (p * KNB + col) * 3;
+                o[0] = ax; o[1] = ay; o[2] = az;
+            }
+            const float sx = wave_sum(ax), sy = wave_sum(ay), sz = wave_sum(az);  // every neighbour sits in both lane halves
+            if (lane == 0) {
+                d_xyz1[p * 3 + 0] = -0.5f * sx;
+                d_xyz1[p * 3 + 1] = -0.5f * sy;
+                d_xyz1[p * 3 + 2] = -0.5f * sz;
+            }
+        }
+        // ---- sums over the neighbours with lane = channel: dL/dpoints1 (= this point's share of dbpos), dWpos ----
+        __builtin_amdgcn_wave_barrier();
+        write_tiles<T>(tb, du, col, h);
+        if (h == 0) dirb[col] = make_float4(dx, dy, dzc, 0.f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int mt = 0; mt < T; ++mt) {
+            float rowsum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+                read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 dj = dirb[16 * ks + 8 * h + i];
+                    dWp[mt][0] = __builtin_fmaf(v[i], dj.x, dWp[mt][0]);
+                    dWp[mt][1] = __builtin_fmaf(v[i], dj.y, dWp[mt][1]);
+                    dWp[mt][2] = __builtin_fmaf(v[i], dj.z, dWp[mt][2]);
+                    rowsum += v[i];
+                }
+            }
+            rowsum += __shfl_xor(rowsum, 32);
+            if (h == 0) {
+                d_points1[p * D + 32 * mt + col] = rowsum;
+                dbp[mt] += rowsum;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- the workgroup's partial vector: waves added in wave order through LDS (over the weight images, no longer needed) ----
+    __syncthreads();
+    float *red = lds;
+#pragma unroll 1
+    for (int w = 0; w < WAVES; ++w) {
+        if (wave == w) {
+            const bool first = w == 0;
+#pragma unroll
+            for (int mt = 0; mt < T; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < T; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float *o = red + S::G_WM + (32 * mt + chan_of(r, h)) * D + 32 * nt + col;
+                        *o = first ? dWa[mt][nt][r] : *o + dWa[mt][nt][r];
+                    }
+                const float vb = dbm[mt] + __shfl_xor(dbm[mt], 32);
+                float vw[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vw[k] = dWp[mt][k] + __shfl_xor(dWp[mt][k], 32);
+                if (h == 0) {
+                    const int c = 32 * mt + col;
+                    red[S::G_BM + c] = first ? vb : red[S::G_BM + c] + vb;
+                    red[S::G_BP + c] = first ? dbp[mt] : red[S::G_BP + c] + dbp[mt];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) red[S::G_WP + c * 3 + k] = first ? vw[k] : red[S::G_WP + c * 3 + k] + vw[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < S::G_FLOATS; e += 64 * WAVES) partial[(size_t)blockIdx.x * S::G_FLOATS + e] = red[e];
+}
+
+// out[e] = sum over the workgroups' partial vectors, in workgroup order
+__global__ __launch_bounds__(256) void cross_grad_reduce_kernel(const float *__restrict__ partial, int parts, int floats, float *__restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= floats) return;
+    float s = 0.f;
+    for (int g = 0; g < parts; ++g) s += partial[(size_t)g * floats + e];
+    out[e] = s;
+}
+
+unsigned grad_grid(long long total, int waves) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const long long want = (total + waves - 1) / waves;
+    return (unsigned)(want < cus ? want : cus);  // one resident workgroup per CU, points dealt out statically
+}
+
+template <int D>
+int launch_cross_grad(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2, const int *idx,
+                      const int *idx2, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, const float *gout, float *d_xyz1,
+                      float *d_dir, float *d_points1, float *d_rows, float *d_weights, float *workspace, hipStream_t s) {
+    using S = GradShape<D>;
+    auto kern = cross_grad_kernel<D>;
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_once.done();
+    }
+    const unsigned grid = grad_grid(total, S::WAVES);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * S::WAVES), S::LDS_BYTES, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, wpos, bpos, wmlp,
+                       bmlp, gout, d_xyz1, d_dir, d_points1, d_rows, workspace);
+    hipLaunchKernelGGL(cross_grad_reduce_kernel, dim3((S::G_FLOATS + 255) / 256), dim3(256), 0, s, workspace, (int)grid, S::G_FLOATS, d_weights);
+    return mcp_launch_status();
+}
+
+}  // namespace
+
+MCP_EXPORT int mcp_cross_grad_floats(int d) { return d == 64 ? GradShape<64>::G_FLOATS : 0; }
+
+MCP_EXPORT size_t mcp_cross_grad_workspace_bytes(int b, int n1, int d) {
+    if (b <= 0 || n1 <= 0 || d != 64) return 0;
+    return (size_t)grad_grid((long long)b * n1, GradShape<64>::WAVES) * GradShape<64>::G_FLOATS * sizeof(float);
+}
+
+MCP_EXPORT int mcp_cross_grad(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
+                              const int *idx, const int *idx2, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp,
+                              const float *grad_out, float *grad_xyz1, float *grad_dir, float *grad_points1, float *grad_rows, float *grad_weights,
+                              void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && wpos && bpos && wmlp && bmlp && grad_out && grad_xyz1 &&
+                   grad_dir && grad_points1 && grad_rows && grad_weights && workspace);
+    if (k != KNB || d != 64) return MCP_ERR_UNSUPPORTED;
+    if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)grad_out) | ((uintptr_t)grad_rows)) & 15) return MCP_ERR_BAD_ARG;
+    if (workspace_bytes < mcp_cross_grad_workspace_bytes(b, n1, d)) return MCP_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    mcp_prof_begin(MCP_KERNEL_CROSS, s);
+    const int rc = launch_cross_grad<64>((long long)b * n1, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, wpos, bpos, wmlp, bmlp, grad_out, grad_xyz1,
+                                         grad_dir, grad_points1, grad_rows, grad_weights, static_cast<float *>(workspace), s);
+    mcp_prof_end(MCP_KERNEL_CROSS, s);
+    return rc;
+}

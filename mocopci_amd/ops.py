@@ -74,19 +74,68 @@ class _GroupRowsFn(torch.autograd.Function):
         return _group_rows_grad(grad_out, idx, ctx.n), None
 
 
-def _group_rows_grad(grad_out, idx, n):
+def _scatter_segments(idx, n):
+    """(order, seg) of a gather list (B,...) into rows 0..n-1: the gather positions sorted by destination row (stable) and the row
+    boundaries in that order -- the operands of mcp_group_rows_grad_sorted; one pair serves every tensor gathered with the list."""
+    B = idx.shape[0]
+    T = idx[0].numel()
+    keys, order = torch.sort(idx.reshape(B, T), dim=1, stable=True)
+    bounds = torch.arange(n + 1, device=idx.device, dtype=keys.dtype).expand(B, n + 1).contiguous()
+    seg = torch.searchsorted(keys.contiguous(), bounds).int()
+    return order.int().contiguous(), seg.contiguous()
+
+
+def _group_rows_grad(grad_out, idx, n, segments=None):
     """Scatter-add of gathered rows' gradients (B,...,C) back to (B,n,C) as a deterministic segmented reduction: stable sort of the
     gather positions by destination row, in-order sums per row."""
     B, C = grad_out.shape[0], grad_out.shape[-1]
     T = idx[0].numel()
     grad_out = grad_out.contiguous()
-    keys, order = torch.sort(idx.reshape(B, T), dim=1, stable=True)
-    bounds = torch.arange(n + 1, device=idx.device, dtype=keys.dtype).expand(B, n + 1).contiguous()
-    seg = torch.searchsorted(keys.contiguous(), bounds).int()
+    order, seg = segments if segments is not None else _scatter_segments(idx, n)
     grad_rows = torch.empty((B, n, C), dtype=torch.float32, device=grad_out.device)
-    _call("mcp_group_rows_grad_sorted", grad_out, B, n, C, T, _lib.fptr(grad_out), _lib.iptr(order.int().contiguous()), _lib.iptr(seg.contiguous()),
-          _lib.fptr(grad_rows))
+    _call("mcp_group_rows_grad_sorted", grad_out, B, n, C, T, _lib.fptr(grad_out), _lib.iptr(order), _lib.iptr(seg), _lib.fptr(grad_rows))
     return grad_rows
+
+
+class _CrossFn(torch.autograd.Function):
+    """mcp_cross_volume with its hand-written backward (mcp_cross_grad, D = 64): recompute inside the backward kernel, the
+    per-neighbour gradients through the deterministic segmented scatter (one sort serves both), weight gradients fixed-order sums."""
+
+    @staticmethod
+    def forward(ctx, be, ia, ib, xyz1, xyz2, points1, points2, wpos, bpos, wmlp, bmlp):
+        args = [t.detach().contiguous() for t in (xyz1, xyz2, points1, points2, wpos, bpos, wmlp, bmlp)]
+        ctx.save_for_backward(ia, ib, *args)
+        return be.cross_volume(*args[:4], ia if ib is None else (ia, ib), be.cross_pack(*args[4:]))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ia, ib, xyz1, xyz2, points1, points2, wpos, bpos, wmlp, bmlp = ctx.saved_tensors
+        B, N1, D = points1.shape
+        N2 = xyz2.shape[1]
+        lib, dev = _lib.load(), points1.device
+        grad_out = grad_out.contiguous()
+        d_xyz1, d_points1 = torch.empty_like(xyz1), torch.empty_like(points1)
+        d_dir = torch.empty((B, N1, 32, 3), dtype=torch.float32, device=dev)
+        d_rows = torch.empty((B, N1, 32, D), dtype=torch.float32, device=dev)
+        d_w = torch.empty((lib.mcp_cross_grad_floats(D),), dtype=torch.float32, device=dev)
+        need = lib.mcp_cross_grad_workspace_bytes(B, N1, D)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _call("mcp_cross_grad", points1, B, N1, N2, D, 32, _lib.fptr(xyz1), _lib.fptr(xyz2), _lib.fptr(points1), _lib.fptr(points2), _lib.iptr(ia),
+              None if ib is None else _lib.iptr(ib), _lib.fptr(wpos), _lib.fptr(bpos), _lib.fptr(wmlp), _lib.fptr(bmlp), _lib.fptr(grad_out),
+              _lib.fptr(d_xyz1), _lib.fptr(d_dir), _lib.fptr(d_points1), _lib.fptr(d_rows), _lib.fptr(d_w), ws.data_ptr(), need)
+        d_xyz2 = d_points2 = None
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[6]:
+            whole = ia if ib is None else torch.cat((ia, ib), dim=-1)
+            segments = _scatter_segments(whole, N2)
+            if ctx.needs_input_grad[4]:
+                d_xyz2 = _group_rows_grad(d_dir, whole, N2, segments)
+            if ctx.needs_input_grad[6]:
+                d_points2 = _group_rows_grad(d_rows, whole, N2, segments)
+        pieces, at = [], 0
+        for t in (wpos, bpos, wmlp, bmlp):
+            pieces.append(d_w[at:at + t.numel()].view(t.shape))
+            at += t.numel()
+        return (None, None, None, d_xyz1, d_xyz2, d_points1, d_points2, *pieces)
 
 
 class _FusionFn(torch.autograd.Function):
@@ -373,6 +422,9 @@ class HipBackend:
             return self.cross_volume(x1.contiguous(), x2.contiguous(), f1.contiguous(), f2.contiguous(), i, pk, bmap=bmap, shared=shared)
         if bmap is not None:
             return fused(xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp)
+        if grad.wants_grad(xyz1, xyz2, points1, points2, wpos, bpos, wmlp, bmlp) and _lib.load().mcp_cross_grad_floats(wmlp.shape[0]):
+            ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
+            return _CrossFn.apply(self, ia.contiguous(), None if ib is None else ib.contiguous(), xyz1, xyz2, points1, points2, wpos, bpos, wmlp, bmlp)
         return grad.run(fused, lambda *a: grad.cross_twin(self.group_rows, *a), xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp)
 
     def ptblock_layer(self, xyz, q, k, v, idx, weights, packed=None):

@@ -123,6 +123,35 @@ def test_fusion_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bi
         assert err <= 2e-4 * scale + 2e-5, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
 
 
+def test_cross_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bit():
+    """mcp_cross_grad (D = 64) against autograd over the unfused layer (grad.cross_twin) on the device: the neighbour list as the two
+    searches' 16 + 16 halves -- which overlap, so equal maxima between list positions are the common case and the kernel's
+    lowest-position rule must give the same total as autograd's choice -- n1 != n2, a ragged last workgroup; two runs, same bits."""
+    from mocopci_amd import grad
+    be = ops.backend()
+    n1, n2, d = 1237, 1500, 64
+    xyz1, xyz2 = cloud(140, 3, n1).to(DEV), cloud(141, 3, n2).to(DEV)
+    f1, f2 = rnd(142, 3, n1, d).to(DEV), rnd(143, 3, n2, d).to(DEV)
+    halves = (be.knn(xyz1, xyz2, 16), be.knn(xyz1, xyz2, 16))           # identical halves: every maximum is tied between two positions
+    w = [rnd(144, d, 3, scale=0.3), rnd(145, d, scale=0.1), rnd(146, d, d, scale=d ** -0.5), rnd(147, d, scale=0.1)]
+    g = rnd(148, 3, n1, d).to(DEV)
+    names = ["xyz1", "xyz2", "points1", "points2", "wpos", "bpos", "wmlp", "bmlp"]
+
+    def grads(fn, idx):
+        leaves = [t.detach().clone().to(DEV).requires_grad_(True) for t in (xyz1, xyz2, f1, f2, *w)]
+        return torch.autograd.grad(fn(*leaves[:4], idx, *leaves[4:]), leaves, g)
+    for idx in (halves, be.knn(xyz1, xyz2, 32)):                        # ... and one (B,N1,32) list of distinct neighbours
+        hip = grads(be.cross_layer, idx)
+        again = grads(be.cross_layer, idx)
+        want = grads(lambda a, b, c, e, i, *ww: grad.cross_twin(be.group_rows, a, b, c, e, i, *ww), idx)
+        for name, a, a2, b in zip(names, hip, again, want):
+            assert torch.equal(a, a2), name
+            assert torch.isfinite(a).all(), name
+            scale = float(b.abs().max())
+            err = float((a - b).abs().max())
+            assert err <= 2e-4 * scale + 2e-5, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
+
+
 def test_ptblock_gradients():
     n = 333
     xyz = cloud(40, 2, n)
