@@ -280,6 +280,22 @@ int mcp_pointconv_agg(int b, int n, int s, int d, int k, const float *s_xyz, con
                       const int *idx, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                       const float *b2, float *out, mcp_stream_t stream);
 
+/* Backward of mcp_pointconv_agg (the reference differentiates mocopci.py:1330-1335 with autograd over the materialised (B,S,32,3+D)
+ * grouping; its hand-written backward pieces are the atomicAdd scatters of group_points_gpu.cu:8-44).  Arguments as
+ * mcp_pointconv_agg, plus grad_out (B,S,(3+D)*8) = dL/dout, 16-byte aligned.  Writes
+ *   grad_new_xyz (B,S,3);
+ *   grad_gxyz (B,S,32,3) and grad_rows (B,S,32,D): dL/d(s_xyz[idx]) and dL/d(s_points[idx]) per gathered neighbour -- the caller
+ *       scatters them with mcp_group_rows_grad_sorted (deterministic);
+ *   grad_weights: mcp_pointconv_agg_grad_floats() = 176 floats: dW0 (8,3) | db0 (8) | dW1 (8,8) | db1 (8) | dW2 (8,8) | db2 (8).
+ * The WeightNet is re-evaluated per (centre, neighbour) pair; all sums run in fixed orders (results repeat bit for bit).
+ * workspace: mcp_pointconv_agg_grad_workspace_bytes(b, s) bytes.  k = 32; d a multiple of 4, 4 <= d <= 256. */
+int mcp_pointconv_agg_grad_floats(void);
+size_t mcp_pointconv_agg_grad_workspace_bytes(int b, int s);
+int mcp_pointconv_agg_grad(int b, int n, int s, int d, int k, const float *s_xyz, const float *new_xyz, const float *s_points, const int *idx,
+                           const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
+                           const float *grad_out, float *grad_new_xyz, float *grad_gxyz, float *grad_rows, float *grad_weights,
+                           void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+
 /* PointConv / PointConvD after the sampling as ONE launch (models/m_models/mocopci.py:1330-1342 and :1381-1393: group + WeightNet +
  * matmul + Linear((3+D)*8 -> C_out) + LeakyReLU): the (B,S,(3+D)*8) aggregate stays on the compute unit.  Arguments as
  * mcp_pointconv_agg, then `packed`: the mcp_linear_pack image of the Linear's (C_out, (3+D)*8) weight (one piece) with its bias;

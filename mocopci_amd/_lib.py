@@ -59,6 +59,9 @@ SIGNATURES = {
     "mcp_cross_grad_workspace_bytes": [_i, _i, _i],
     "mcp_cross_grad": [_i] * 5 + [_p] * 17 + [ctypes.c_size_t, _p],
     "mcp_pointconv_agg": [_i] * 5 + [_p] * 12,
+    "mcp_pointconv_agg_grad_floats": [],
+    "mcp_pointconv_agg_grad_workspace_bytes": [_i, _i],
+    "mcp_pointconv_agg_grad": [_i] * 5 + [_p] * 16 + [ctypes.c_size_t, _p],
     "mcp_pointconv_linear": [_i] * 5 + [_p] * 11 + [_i, _f, _p, _p],
     "mcp_attention_small": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
     "mcp_attention_wide": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
@@ -82,7 +85,7 @@ SIGNATURES = {
     "mcp_prof_collect": [_i, _p, _p],
 }
 _RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": ctypes.c_size_t, "mcp_fusion_grad_workspace_bytes": ctypes.c_size_t,
-             "mcp_cross_grad_workspace_bytes": ctypes.c_size_t}
+             "mcp_cross_grad_workspace_bytes": ctypes.c_size_t, "mcp_pointconv_agg_grad_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

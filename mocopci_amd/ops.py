@@ -97,6 +97,46 @@ def _group_rows_grad(grad_out, idx, n, segments=None):
     return grad_rows
 
 
+class _PointConvAggFn(torch.autograd.Function):
+    """mcp_pointconv_agg with its hand-written backward (mcp_pointconv_agg_grad): WeightNet recomputed per (centre, neighbour) pair in
+    the backward kernel, per-neighbour gradients through the deterministic segmented scatter, weight gradients fixed-order sums."""
+
+    @staticmethod
+    def forward(ctx, be, idx, s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2):
+        args = [t.detach().contiguous() for t in (s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2)]
+        ctx.save_for_backward(idx, *args)
+        return be._pointconv_agg(*args[:3], idx, *args[3:])
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2 = ctx.saved_tensors
+        B, N, D = s_points.shape
+        S = new_xyz.shape[1]
+        lib, dev = _lib.load(), s_points.device
+        grad_out = grad_out.contiguous()
+        d_new = torch.empty_like(new_xyz)
+        d_gxyz = torch.empty((B, S, 32, 3), dtype=torch.float32, device=dev)
+        d_rows = torch.empty((B, S, 32, D), dtype=torch.float32, device=dev)
+        d_w = torch.empty((lib.mcp_pointconv_agg_grad_floats(),), dtype=torch.float32, device=dev)
+        need = lib.mcp_pointconv_agg_grad_workspace_bytes(B, S)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _call("mcp_pointconv_agg_grad", s_points, B, N, S, D, 32, _lib.fptr(s_xyz), _lib.fptr(new_xyz), _lib.fptr(s_points), _lib.iptr(idx),
+              _lib.fptr(w0), _lib.fptr(b0), _lib.fptr(w1), _lib.fptr(b1), _lib.fptr(w2), _lib.fptr(b2), _lib.fptr(grad_out), _lib.fptr(d_new),
+              _lib.fptr(d_gxyz), _lib.fptr(d_rows), _lib.fptr(d_w), ws.data_ptr(), need)
+        d_sxyz = d_spoints = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[4]:
+            segments = _scatter_segments(idx, N)
+            if ctx.needs_input_grad[2]:
+                d_sxyz = _group_rows_grad(d_gxyz, idx, N, segments)
+            if ctx.needs_input_grad[4]:
+                d_spoints = _group_rows_grad(d_rows, idx, N, segments)
+        pieces, at = [], 0
+        for t in (w0, b0, w1, b1, w2, b2):
+            pieces.append(d_w[at:at + t.numel()].view(t.shape))
+            at += t.numel()
+        return (None, None, d_sxyz, d_new, d_spoints, *pieces)
+
+
 class _CrossFn(torch.autograd.Function):
     """mcp_cross_volume with its hand-written backward (mcp_cross_grad, D = 64): recompute inside the backward kernel, the
     per-neighbour gradients through the deterministic segmented scatter (one sort serves both), weight gradients fixed-order sums."""
@@ -456,8 +496,13 @@ class HipBackend:
 
     def pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
         """PointConv grouping + WeightNet + aggregation (mocopci.py:1330-1335): -> (B,S,(3+D)*8).  Differentiable."""
-        return grad.run(self._pointconv_agg, lambda *a: grad.pointconv_agg_twin(self.group_rows, *a), s_xyz, new_xyz, s_points, idx,
-                        w0, b0, w1, b1, w2, b2)
+        D = s_points.shape[-1]
+        if not grad.wants_grad(s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2):
+            return self._pointconv_agg(s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2)
+        if idx.shape[-1] != 32 or D % 4 or D > 256 or tuple(w2.shape) != (8, 8):   # shapes the backward kernel is not built for
+            return grad.run(self._pointconv_agg, lambda *a: grad.pointconv_agg_twin(self.group_rows, *a), s_xyz, new_xyz, s_points, idx,
+                            w0, b0, w1, b1, w2, b2)
+        return _PointConvAggFn.apply(self, idx.contiguous(), s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2)
 
     def _pointconv_agg(self, s_xyz, new_xyz, s_points, idx, w0, b0, w1, b1, w2, b2):
         s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2 = (t.contiguous() for t in (s_xyz, new_xyz, s_points, w0, b0, w1, b1, w2, b2))

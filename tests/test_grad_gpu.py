@@ -152,6 +152,34 @@ def test_cross_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bit
             assert err <= 2e-4 * scale + 2e-5, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
 
 
+@pytest.mark.parametrize("n,s,d", [(1500, 1500, 32), (2000, 501, 64), (600, 150, 128)])
+def test_pointconv_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bit(n, s, d):
+    """mcp_pointconv_agg_grad against autograd over the unfused layer (grad.pointconv_agg_twin) on the device, odd centre counts (the
+    last wave holds one centre), PointConv (s = n) and PointConvD (s < n) forms; two runs give identical bits."""
+    from mocopci_amd import grad
+    be = ops.backend()
+    s_xyz = cloud(150 + d, 3, n).to(DEV)
+    new_xyz = s_xyz[:, :s].clone()
+    pts = rnd(151, 3, n, d).to(DEV)
+    idx = be.knn(new_xyz, s_xyz, 32)
+    wn = [rnd(152, 8, 3, scale=0.5), rnd(153, 8, scale=0.1), rnd(154, 8, 8, scale=0.4), rnd(155, 8, scale=0.1), rnd(156, 8, 8, scale=0.4), rnd(157, 8, scale=0.1)]
+    g = rnd(158, 3, s, (d + 3) * 8).to(DEV)
+    names = ["s_xyz", "new_xyz", "points", "w0", "b0", "w1", "b1", "w2", "b2"]
+
+    def grads(fn):
+        leaves = [t.detach().clone().to(DEV).requires_grad_(True) for t in (s_xyz, new_xyz, pts, *wn)]
+        return torch.autograd.grad(fn(*leaves), leaves, g)
+    hip = grads(lambda a, b, c, *w: be.pointconv_agg(a, b, c, idx, *w))
+    again = grads(lambda a, b, c, *w: be.pointconv_agg(a, b, c, idx, *w))
+    want = grads(lambda a, b, c, *w: grad.pointconv_agg_twin(be.group_rows, a, b, c, idx, *w))
+    for name, a, a2, b in zip(names, hip, again, want):
+        assert torch.equal(a, a2), name
+        assert torch.isfinite(a).all(), name
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        assert err <= 2e-4 * scale + 2e-5, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
+
+
 def test_ptblock_gradients():
     n = 333
     xyz = cloud(40, 2, n)
