@@ -262,8 +262,8 @@ int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float *xyz1, con
  *   grad_weights: mcp_cross_grad_floats(d) floats = dWpos (D,3) | dbpos (D) | dWmlp (D,D) | dbmlp (D).
  * The layer is re-evaluated in the kernel; the arg-max neighbour of a channel is the lowest list position among equal maxima;
  * all sums run in fixed orders (results repeat bit for bit).  workspace: mcp_cross_grad_workspace_bytes(b, n1, d) bytes.
- * D = 64 (the level-1 cost volumes, 70 % of the layer's backward time at the training shape); other D: MCP_ERR_UNSUPPORTED,
- * mcp_cross_grad_floats returns 0. */
+ * D = 64 and 128 (the level-1 and level-2 cost volumes, 97 % of the layer's backward time at the training shape); D = 256:
+ * MCP_ERR_UNSUPPORTED, mcp_cross_grad_floats returns 0 (the caller differentiates the unfused layer).  workspace 16-byte aligned. */
 int mcp_cross_grad_floats(int d);
 size_t mcp_cross_grad_workspace_bytes(int b, int n1, int d);
 int mcp_cross_grad(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1, const float *points2,

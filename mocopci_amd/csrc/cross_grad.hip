@@ -52,16 +52,23 @@ template <int D>
 struct GradShape {
     static constexpr int T = D / 32;
     static constexpr int WAVES = 4;
+    // D = 128: the 256 accumulator registers of dWmlp do not fit beside the rest, so the workgroups come in three ROLES that all walk
+    // every point: the data role (x, all of z, dx, the per-neighbour outputs, dWpos: 384 MFMAs per point) and two dWmlp roles that
+    // own rows 0..63 / 64..127 and re-evaluate only what those need (x and their two z tiles: 192 MFMAs) -- grid shares 2 : 1 : 1.
+    // D = 64: one role does both.
+    static constexpr int ROLES = D == 64 ? 1 : 3;
+    static constexpr bool WT_LDS = D == 64;  // the Wmlp^T image: in LDS beside Wmlp (D = 64), or read from the workspace through L2 (98 KB at D = 128)
     // weight-gradient vector (floats): dWpos (D,3) | dbpos (D) | dWmlp (D,D) | dbmlp (D)
     static constexpr int G_WP = 0, G_BP = 3 * D, G_WM = 4 * D, G_BM = 4 * D + D * D, G_FLOATS = G_BM + D;
     // LDS, floats: pos image [t][s][lane] | bmlp [t][h][r] | Wpos rows [t][h][r][4]
     static constexpr int L_POS = 0, L_B = T * 2 * 64, L_WPR = L_B + T * 32, L_F32 = L_WPR + T * 32 * 4;
     static constexpr int W_U4 = T * (2 * T) * 3 * 64;  // uint4 per split image (Wmlp, Wmlp^T)
-    // per wave (floats): tile [D][TS] | directions [32][4]
-    static constexpr int S_T = 0, S_DIR = D * TS, S_FLOATS = S_DIR + 128;
-    static constexpr size_t LDS_BYTES = (size_t)L_F32 * 4 + (size_t)2 * W_U4 * 16 + (size_t)WAVES * S_FLOATS * 4;
+    static constexpr int W_LDS_U4 = WT_LDS ? 2 * W_U4 : W_U4;
+    // per wave (floats): tile [64][TS] (two 32-channel tiles at a time) | directions [32][4]
+    static constexpr int S_T = 0, S_DIR = 64 * TS, S_FLOATS = S_DIR + 128;
+    static constexpr size_t LDS_BYTES = (size_t)L_F32 * 4 + (size_t)W_LDS_U4 * 16 + (size_t)WAVES * S_FLOATS * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert((size_t)G_FLOATS * 4 <= (size_t)L_F32 * 4 + (size_t)2 * W_U4 * 16, "the reduction buffer overlays the weight images");
+    static_assert((size_t)G_FLOATS * 4 <= (size_t)L_F32 * 4 + (size_t)W_LDS_U4 * 16, "the reduction buffer overlays the weight images");
 };
 
 __device__ __forceinline__ void split_weights_transposed(uint4 *dst, const float *__restrict__ w, int m_total, int k_total, int first, int stride) {
@@ -78,17 +85,21 @@ __device__ __forceinline__ void split_weights_transposed(uint4 *dst, const float
         o[128] = sp.p3;
     }
 }
+__global__ __launch_bounds__(256) void transposed_image_kernel(uint4 *dst, const float *__restrict__ w, int d) {
+    split_weights_transposed(dst, w, d, d, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
 
 __device__ __forceinline__ void read8(const float *row, float *v) {
     const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
-template <int T>
-__device__ __forceinline__ void write_tiles(float *tb, const f32x16 *v, int col, int h) {
+// two accumulator-layout tiles (64 channels x 32 neighbours) into the tile buffer: row = channel, column = neighbour
+__device__ __forceinline__ void write_pair(float *tb, const f32x16 &a, const f32x16 &b, int col, int h) {
 #pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tb[(32 * t + chan_of(r, h)) * TS + col] = v[t][r];
+    for (int r = 0; r < 16; ++r) {
+        tb[chan_of(r, h) * TS + col] = a[r];
+        tb[(32 + chan_of(r, h)) * TS + col] = b[r];
+    }
 }
 __device__ __forceinline__ f32x16 mfma_split6(const McpSplit3 &a, const McpSplit3 &b, f32x16 acc) {
     acc = mcp_mfma_bf16(a.p3, b.p1, acc);
@@ -100,19 +111,26 @@ __device__ __forceinline__ f32x16 mfma_split6(const McpSplit3 &a, const McpSplit
     return acc;
 }
 
-template <int D>
-__global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel(
-    long long total, int n1, int n2, const float *__restrict__ xyz1, const float *__restrict__ xyz2, const float *__restrict__ points1,
-    const float *__restrict__ points2, const int *__restrict__ idx, const int *__restrict__ idx2, const float *__restrict__ wpos,
-    const float *__restrict__ bpos, const float *__restrict__ wmlp, const float *__restrict__ bmlp, const float *__restrict__ gout,
-    float *__restrict__ d_xyz1, float *__restrict__ d_dir, float *__restrict__ d_points1, float *__restrict__ d_rows, float *__restrict__ partial) {
+// One workgroup of a role: points first, first + step, ... of the launch.  DATA: dx, the per-neighbour outputs, dWpos;
+// OWN >= 0: rows 32 OWN .. 32 OWN + 63 of dWmlp (and of dbmlp).
+template <int D, bool DATA, int OWN>
+__device__ __forceinline__ void cross_grad_body(float *lds, long long total, int n1, int n2, long long first, long long step, const float *__restrict__ xyz1,
+                                                const float *__restrict__ xyz2, const float *__restrict__ points1, const float *__restrict__ points2,
+                                                const int *__restrict__ idx, const int *__restrict__ idx2, const float *__restrict__ wpos,
+                                                const float *__restrict__ bpos, const float *__restrict__ wmlp, const float *__restrict__ bmlp,
+                                                const uint4 *__restrict__ wt_global, const float *__restrict__ gout, float *__restrict__ d_xyz1,
+                                                float *__restrict__ d_dir, float *__restrict__ d_points1, float *__restrict__ d_rows,
+                                                float *__restrict__ partial_row) {
     using S = GradShape<D>;
     constexpr int T = S::T, WAVES = S::WAVES;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool HAS_OWN = OWN >= 0;
+    constexpr int OWN0 = HAS_OWN ? OWN : 0;
+    static_assert(!DATA || OWN <= 0, "with DATA the own tiles must come first in the z loop");
     uint4 *wms = reinterpret_cast<uint4 *>(lds + S::L_F32);
-    uint4 *wmts = wms + S::W_U4;
+    uint4 *wmts_lds = wms + S::W_U4;
+    const uint4 *wmts = S::WT_LDS ? wmts_lds : wt_global;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
-    float *scr = reinterpret_cast<float *>(wmts + S::W_U4) + wave * S::S_FLOATS;
+    float *scr = reinterpret_cast<float *>(wms + S::W_LDS_U4) + wave * S::S_FLOATS;
     float *tb = scr + S::S_T;
     float4 *dirb = reinterpret_cast<float4 *>(scr + S::S_DIR);
 
@@ -128,22 +146,23 @@ __global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel
         lds[S::L_B + e] = bmlp[32 * t + chan_of(r, hh)];
     }
     mcp_split_weights(wms, wmlp, D, T, tid, 64 * WAVES);
-    split_weights_transposed(wmts, wmlp, D, D, tid, 64 * WAVES);
+    if (S::WT_LDS) split_weights_transposed(wmts_lds, wmlp, D, D, tid, 64 * WAVES);
     __syncthreads();
 
-    f32x16 dWa[T][T];  // dWmlp tiles: row = 32 mt + chan_of(r, h), column = 32 nt + col
+    f32x16 dWa[2][HAS_OWN ? T : 1];  // dWmlp tiles: row = 32 (OWN + a) + chan_of(r, h), column = 32 nt + col
 #pragma unroll
-    for (int a = 0; a < T; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < T; ++b)
+        for (int b = 0; b < (HAS_OWN ? T : 1); ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dWa[a][b][r] = 0.f;
-    float dbm[T], dbp[T], dWp[T][3];  // lane = channel 32 mt + col; the two lane halves hold the two 8-neighbour groups
+    float dbm[2] = {0.f, 0.f};  // lane = channel 32 (OWN + a) + col; the two lane halves hold the two 8-neighbour groups
+    float dbp[T], dWp[T][3];    // lane = channel 32 mt + col
 #pragma unroll
-    for (int t = 0; t < T; ++t) { dbm[t] = 0.f; dbp[t] = 0.f; dWp[t][0] = 0.f; dWp[t][1] = 0.f; dWp[t][2] = 0.f; }
+    for (int t = 0; t < T; ++t) { dbp[t] = 0.f; dWp[t][0] = 0.f; dWp[t][1] = 0.f; dWp[t][2] = 0.f; }
     const uint32_t lower_lanes = (1u << col) - 1u;
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    for (long long p = first + wave; p < total; p += step) {
         const long long bb = mcp_div(p, n1, mcp_fits32(total));
         const int id = idx2 ? (col >= 16 ? idx2[p * 16 + col - 16] : idx[p * 16 + col]) : idx[p * KNB + col];
         const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
@@ -152,8 +171,9 @@ __global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel
         const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)bb * n2 + id) * D);
         const float4 *row1 = reinterpret_cast<const float4 *>(points1 + p * D);
         const float4 *grow = reinterpret_cast<const float4 *>(gout + p * D);
-        // ---- the forward again: x = LeakyReLU(points2[idx] + points1 + pos), z = Wmlp x + b ----
-        f32x16 x[T];
+        // ---- the forward again: x = LeakyReLU(points2[idx] + points1 + pos) ----
+        f32x16 x[T], du[DATA ? T : 1];
+        McpSplit3 as[2][2];
         {
             McpSplit3 xs[2 * T];
 #pragma unroll
@@ -179,14 +199,25 @@ __global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel
                 xs[2 * t + 0] = mcp_split_kstep(acc, 0);
                 xs[2 * t + 1] = mcp_split_kstep(acc, 1);
             }
-            // z tile by tile; dz_j[c] = g[c] LeakyReLU'(z_j[c]) at the arg-max neighbour (lowest position among equals), 0 elsewhere
+            if (DATA) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) du[DATA ? t : 0][r] = 0.f;
+            }
+            // z = Wmlp x + b tile by tile (this role's own tiles first); dz_j[c] = g[c] LeakyReLU'(z_j[c]) at the arg-max neighbour
+            // (lowest list position among equals), 0 elsewhere.  Own tiles go into the transposition tile (the A operand of
+            // dWmlp); with DATA every tile's dz is folded into dx = Wmlp^T dz right away, as two k-steps of each output tile.
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int tz = 0; tz < (DATA ? T : 2); ++tz) {
+                const int t = DATA ? tz : OWN0 + tz;      // DATA: OWN <= 0, so own tiles (0, 1) come first
+                const bool own = HAS_OWN && (t == OWN0 || t == OWN0 + 1);
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = lds[S::L_B + (t * 2 + h) * 16 + r];
                 acc = mcp_tile_split<2 * T>(wms + (size_t)t * (2 * T) * 3 * 64 + lane, xs, acc);
+                f32x16 dzt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 gv = grow[(32 * t + 8 * g + 4 * h) >> 2];
@@ -200,73 +231,71 @@ __global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel
                         const unsigned long long mask = __builtin_amdgcn_ballot_w64(top);
                         const uint32_t mine = h ? (uint32_t)(mask >> 32) : (uint32_t)mask;
                         const bool winner = top && (mine & lower_lanes) == 0u;
-                        // written into the transposition tile right away (row = channel, column = neighbour): the A operand of dWmlp
-                        tb[(32 * t + chan_of(r, h)) * TS + col] = winner ? (zv > 0.f ? gq[i] : SLOPE * gq[i]) : 0.f;
+                        dzt[r] = winner ? (zv > 0.f ? gq[i] : SLOPE * gq[i]) : 0.f;
+                        if (own) tb[(32 * (t - OWN0) + chan_of(r, h)) * TS + col] = dzt[r];
                     }
                 }
+                if (DATA) {
+                    const McpSplit3 z0 = mcp_split_kstep(dzt, 0), z1 = mcp_split_kstep(dzt, 1);
+#pragma unroll
+                    for (int to = 0; to < T; ++to) {
+                        const uint4 *wk = wmts + ((size_t)to * (2 * T) + 2 * t) * 3 * 64 + lane;
+                        du[DATA ? to : 0] = mcp_mfma_split(wk, z0, du[DATA ? to : 0]);
+                        du[DATA ? to : 0] = mcp_mfma_split(wk + 3 * 64, z1, du[DATA ? to : 0]);
+                    }
+                }
+                if (HAS_OWN && tz == 1) {  // both own tiles are in the transposition tile: dWmlp's A operand, dbmlp
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            float v[8];
+                            read8(tb + (32 * a + col) * TS + 16 * ks + 8 * h, v);
+                            dbm[a] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                            as[a][ks] = mcp_split8(v);
+                        }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
+        }
+        // ---- dWmlp (own rows) += dz . x^T, x through the transposition tile two 32-channel tiles at a time ----
+#pragma unroll
+        for (int hb = 0; hb < (HAS_OWN ? T / 2 : 0); ++hb) {
             __builtin_amdgcn_wave_barrier();
+            write_pair(tb, x[2 * hb], x[2 * hb + 1], col, h);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[8];
+                    read8(tb + (32 * tt + col) * TS + 16 * ks + 8 * h, v);
+                    const McpSplit3 bs = mcp_split8(v);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) dWa[a][HAS_OWN ? 2 * hb + tt : 0] = mfma_split6(as[a][ks], bs, dWa[a][HAS_OWN ? 2 * hb + tt : 0]);
+                }
         }
-        // ---- dWmlp += dz . x^T, dbmlp ----
-        McpSplit3 as[T][2];
+        if (DATA) {
+            // ---- du = LeakyReLU'(u) . dx;  per-neighbour outputs: d_rows = du, d_dir = Wpos^T du ----
 #pragma unroll
-        for (int mt = 0; mt < T; ++mt)
+            for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float v[8];
-                read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
-                dbm[mt] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                as[mt][ks] = mcp_split8(v);
-            }
-        // dz back in accumulator layout (the B operand of dx = Wmlp^T dz)
-        McpSplit3 zs[2 * T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            f32x16 dzt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dzt[r] = tb[(32 * t + chan_of(r, h)) * TS + col];
-            zs[2 * t + 0] = mcp_split_kstep(dzt, 0);
-            zs[2 * t + 1] = mcp_split_kstep(dzt, 1);
-        }
-        __builtin_amdgcn_wave_barrier();
-        write_tiles<T>(tb, x, col, h);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int nt = 0; nt < T; ++nt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float v[8];
-                read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
-                const McpSplit3 bs = mcp_split8(v);
-#pragma unroll
-                for (int mt = 0; mt < T; ++mt) dWa[mt][nt] = mfma_split6(as[mt][ks], bs, dWa[mt][nt]);
-            }
-        // ---- du = LeakyReLU'(u) . Wmlp^T dz ----
-        f32x16 du[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            acc = mcp_tile_split<2 * T>(wmts + (size_t)t * (2 * T) * 3 * 64 + lane, zs, acc);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) du[t][r] = x[t][r] > 0.f ? acc[r] : SLOPE * acc[r];  // x = LeakyReLU(u) has u's sign
-        }
-        // ---- per-neighbour outputs: d_rows = du, d_dir = Wpos^T du ----
-        {
+                for (int r = 0; r < 16; ++r) du[DATA ? t : 0][r] = x[t][r] > 0.f ? du[DATA ? t : 0][r] : SLOPE * du[DATA ? t : 0][r];  // x = LeakyReLU(u) has u's sign
             float4 *orow = reinterpret_cast<float4 *>(d_rows + (p * KNB + col) * D);
             float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    orow[(32 * t + 8 * g + 4 * h) >> 2] = make_float4(du[t][4 * g + 0], du[t][4 * g + 1], du[t][4 * g + 2], du[t][4 * g + 3]);
+                    const f32x16 &dt = du[DATA ? t : 0];
+                    orow[(32 * t + 8 * g + 4 * h) >> 2] = make_float4(dt[4 * g + 0], dt[4 * g + 1], dt[4 * g + 2], dt[4 * g + 3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float4 w = reinterpret_cast<const float4 *>(lds + S::L_WPR)[(t * 2 + h) * 16 + 4 * g + i];
-                        ax = __builtin_fmaf(w.x, du[t][4 * g + i], ax);
-                        ay = __builtin_fmaf(w.y, du[t][4 * g + i], ay);
-                        az = __builtin_fmaf(w.z, du[t][4 * g + i], az);
+                        ax = __builtin_fmaf(w.x, dt[4 * g + i], ax);
+                        ay = __builtin_fmaf(w.y, dt[4 * g + i], ay);
+                        az = __builtin_fmaf(w.z, dt[4 * g + i], az);
                     }
                 }
             ax += __shfl_xor(ax, 32);
@@ -282,69 +311,102 @@ __global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel
                 d_xyz1[p * 3 + 1] = -0.5f * sy;
                 d_xyz1[p * 3 + 2] = -0.5f * sz;
             }
-        }
-        // ---- sums over the neighbours with lane = channel: dL/dpoints1 (= this point's share of dbpos), dWpos ----
-        __builtin_amdgcn_wave_barrier();
-        write_tiles<T>(tb, du, col, h);
-        if (h == 0) dirb[col] = make_float4(dx, dy, dzc, 0.f);
-        __builtin_amdgcn_wave_barrier();
+            // ---- sums over the neighbours with lane = channel: dL/dpoints1 (= this point's share of dbpos), dWpos ----
 #pragma unroll
-        for (int mt = 0; mt < T; ++mt) {
-            float rowsum = 0.f;
+            for (int hb = 0; hb < T / 2; ++hb) {
+                __builtin_amdgcn_wave_barrier();
+                write_pair(tb, du[DATA ? 2 * hb : 0], du[DATA ? 2 * hb + 1 : 0], col, h);
+                if (hb == 0 && h == 0) dirb[col] = make_float4(dx, dy, dzc, 0.f);
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float v[8];
-                read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int mt = 2 * hb + tt;
+                    float rowsum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 dj = dirb[16 * ks + 8 * h + i];
-                    dWp[mt][0] = __builtin_fmaf(v[i], dj.x, dWp[mt][0]);
-                    dWp[mt][1] = __builtin_fmaf(v[i], dj.y, dWp[mt][1]);
-                    dWp[mt][2] = __builtin_fmaf(v[i], dj.z, dWp[mt][2]);
-                    rowsum += v[i];
+                    for (int ks = 0; ks < 2; ++ks) {
+                        float v[8];
+                        read8(tb + (32 * tt + col) * TS + 16 * ks + 8 * h, v);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float4 dj = dirb[16 * ks + 8 * h + i];
+                            dWp[mt][0] = __builtin_fmaf(v[i], dj.x, dWp[mt][0]);
+                            dWp[mt][1] = __builtin_fmaf(v[i], dj.y, dWp[mt][1]);
+                            dWp[mt][2] = __builtin_fmaf(v[i], dj.z, dWp[mt][2]);
+                            rowsum += v[i];
+                        }
+                    }
+                    rowsum += __shfl_xor(rowsum, 32);
+                    if (h == 0) {
+                        d_points1[p * D + 32 * mt + col] = rowsum;
+                        dbp[mt] += rowsum;
+                    }
                 }
-            }
-            rowsum += __shfl_xor(rowsum, 32);
-            if (h == 0) {
-                d_points1[p * D + 32 * mt + col] = rowsum;
-                dbp[mt] += rowsum;
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- the workgroup's partial vector: waves added in wave order through LDS (over the weight images, no longer needed) ----
+    // ---- the workgroup's partial vector (zero where another role owns the entry): waves added in wave order through LDS ----
     __syncthreads();
     float *red = lds;
+    for (int e = tid; e < S::G_FLOATS; e += 64 * WAVES) red[e] = 0.f;
+    __syncthreads();
 #pragma unroll 1
     for (int w = 0; w < WAVES; ++w) {
         if (wave == w) {
-            const bool first = w == 0;
 #pragma unroll
-            for (int mt = 0; mt < T; ++mt) {
+            for (int a = 0; a < (HAS_OWN ? 2 : 0); ++a) {
 #pragma unroll
                 for (int nt = 0; nt < T; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float *o = red + S::G_WM + (32 * mt + chan_of(r, h)) * D + 32 * nt + col;
-                        *o = first ? dWa[mt][nt][r] : *o + dWa[mt][nt][r];
+                    for (int r = 0; r < 16; ++r) red[S::G_WM + (32 * (OWN0 + a) + chan_of(r, h)) * D + 32 * nt + col] += dWa[a][HAS_OWN ? nt : 0][r];
+                const float vb = dbm[a] + __shfl_xor(dbm[a], 32);
+                if (h == 0) red[S::G_BM + 32 * (OWN0 + a) + col] += vb;
+            }
+            if (DATA) {
+#pragma unroll
+                for (int mt = 0; mt < T; ++mt) {
+                    float vw[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) vw[k] = dWp[mt][k] + __shfl_xor(dWp[mt][k], 32);
+                    if (h == 0) {
+                        const int c = 32 * mt + col;
+                        red[S::G_BP + c] += dbp[mt];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) red[S::G_WP + c * 3 + k] += vw[k];
                     }
-                const float vb = dbm[mt] + __shfl_xor(dbm[mt], 32);
-                float vw[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) vw[k] = dWp[mt][k] + __shfl_xor(dWp[mt][k], 32);
-                if (h == 0) {
-                    const int c = 32 * mt + col;
-                    red[S::G_BM + c] = first ? vb : red[S::G_BM + c] + vb;
-                    red[S::G_BP + c] = first ? dbp[mt] : red[S::G_BP + c] + dbp[mt];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) red[S::G_WP + c * 3 + k] = first ? vw[k] : red[S::G_WP + c * 3 + k] + vw[k];
                 }
             }
         }
         __syncthreads();
     }
-    for (int e = tid; e < S::G_FLOATS; e += 64 * WAVES) partial[(size_t)blockIdx.x * S::G_FLOATS + e] = red[e];
+    for (int e = tid; e < S::G_FLOATS; e += 64 * WAVES) partial_row[e] = red[e];
+}
+
+// Workgroups 0 .. g0-1 take the data role, the next g1 dWmlp's rows 0..63, the rest rows 64..127 (D = 128); every role walks all points.
+template <int D>
+__global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel(
+    long long total, int n1, int n2, int g0, int g1, const float *__restrict__ xyz1, const float *__restrict__ xyz2, const float *__restrict__ points1,
+    const float *__restrict__ points2, const int *__restrict__ idx, const int *__restrict__ idx2, const float *__restrict__ wpos,
+    const float *__restrict__ bpos, const float *__restrict__ wmlp, const float *__restrict__ bmlp, const uint4 *__restrict__ wt_global,
+    const float *__restrict__ gout, float *__restrict__ d_xyz1, float *__restrict__ d_dir, float *__restrict__ d_points1, float *__restrict__ d_rows,
+    float *__restrict__ partial) {
+    using S = GradShape<D>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *prow = partial + (size_t)blockIdx.x * S::G_FLOATS;
+    const int bx = (int)blockIdx.x;
+#define MCP_CROSS_GRAD_ARGS xyz1, xyz2, points1, points2, idx, idx2, wpos, bpos, wmlp, bmlp, wt_global, gout, d_xyz1, d_dir, d_points1, d_rows, prow
+    if (S::ROLES == 1) {
+        cross_grad_body<D, true, 0>(lds, total, n1, n2, (long long)bx * S::WAVES, (long long)g0 * S::WAVES, MCP_CROSS_GRAD_ARGS);
+    } else if (bx < g0) {
+        cross_grad_body<D, true, -1>(lds, total, n1, n2, (long long)bx * S::WAVES, (long long)g0 * S::WAVES, MCP_CROSS_GRAD_ARGS);
+    } else if (bx < g0 + g1) {
+        cross_grad_body<D, false, 0>(lds, total, n1, n2, (long long)(bx - g0) * S::WAVES, (long long)g1 * S::WAVES, MCP_CROSS_GRAD_ARGS);
+    } else {
+        cross_grad_body<D, false, (S::ROLES > 1 ? 2 : 0)>(lds, total, n1, n2, (long long)(bx - g0 - g1) * S::WAVES,
+                                                          (long long)((int)gridDim.x - g0 - g1) * S::WAVES, MCP_CROSS_GRAD_ARGS);
+    }
+#undef MCP_CROSS_GRAD_ARGS
 }
 
 // out[e] = sum over the workgroups' partial vectors, in workgroup order
@@ -356,17 +418,29 @@ __global__ __launch_bounds__(256) void cross_grad_reduce_kernel(const float *__r
     out[e] = s;
 }
 
-unsigned grad_grid(long long total, int waves) {
+// workgroups per role (g0 data, g1 each dWmlp half): one resident workgroup per CU, points dealt out statically within a role
+template <int D>
+void grad_grid(long long total, unsigned *g0, unsigned *g1) {
+    using S = GradShape<D>;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    const long long want = (total + waves - 1) / waves;
-    return (unsigned)(want < cus ? want : cus);  // one resident workgroup per CU, points dealt out statically
+    const long long want = (total + S::WAVES - 1) / S::WAVES;
+    const long long a = S::ROLES == 1 ? cus : (cus / 2 > 0 ? cus / 2 : 1), b = S::ROLES == 1 ? 0 : (cus / 4 > 0 ? cus / 4 : 1);
+    *g0 = (unsigned)(want < a ? want : a);
+    *g1 = (unsigned)(want < b ? want : b);
+}
+template <int D>
+size_t workspace_bytes(long long total) {
+    using S = GradShape<D>;
+    unsigned g0, g1;
+    grad_grid<D>(total, &g0, &g1);
+    return (size_t)(g0 + (S::ROLES - 1) * g1) * S::G_FLOATS * sizeof(float) + (S::WT_LDS ? 0 : (size_t)S::W_U4 * 16);
 }
 
 template <int D>
 int launch_cross_grad(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2, const int *idx,
                       const int *idx2, const float *wpos, const float *bpos, const float *wmlp, const float *bmlp, const float *gout, float *d_xyz1,
-                      float *d_dir, float *d_points1, float *d_rows, float *d_weights, float *workspace, hipStream_t s) {
+                      float *d_dir, float *d_points1, float *d_rows, float *d_weights, void *workspace, hipStream_t s) {
     using S = GradShape<D>;
     auto kern = cross_grad_kernel<D>;
     static McpPerDeviceOnce attr_once;
@@ -375,20 +449,25 @@ int launch_cross_grad(long long total, int n1, int n2, const float *xyz1, const 
         if (e != hipSuccess) return (int)e;
         attr_once.done();
     }
-    const unsigned grid = grad_grid(total, S::WAVES);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * S::WAVES), S::LDS_BYTES, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, wpos, bpos, wmlp,
-                       bmlp, gout, d_xyz1, d_dir, d_points1, d_rows, workspace);
-    hipLaunchKernelGGL(cross_grad_reduce_kernel, dim3((S::G_FLOATS + 255) / 256), dim3(256), 0, s, workspace, (int)grid, S::G_FLOATS, d_weights);
+    unsigned g0, g1;
+    grad_grid<D>(total, &g0, &g1);
+    uint4 *wt = S::WT_LDS ? nullptr : static_cast<uint4 *>(workspace);  // 16-byte aligned: the workspace is, and the image comes first
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + (S::WT_LDS ? 0 : (size_t)S::W_U4 * 16));
+    if (!S::WT_LDS) hipLaunchKernelGGL(transposed_image_kernel, dim3(32), dim3(256), 0, s, wt, wmlp, D);
+    const unsigned grid = g0 + (S::ROLES - 1) * g1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * S::WAVES), S::LDS_BYTES, s, total, n1, n2, (int)g0, (int)g1, xyz1, xyz2, points1, points2, idx, idx2, wpos,
+                       bpos, wmlp, bmlp, wt, gout, d_xyz1, d_dir, d_points1, d_rows, partial);
+    hipLaunchKernelGGL(cross_grad_reduce_kernel, dim3((S::G_FLOATS + 255) / 256), dim3(256), 0, s, partial, (int)grid, S::G_FLOATS, d_weights);
     return mcp_launch_status();
 }
 
 }  // namespace
 
-MCP_EXPORT int mcp_cross_grad_floats(int d) { return d == 64 ? GradShape<64>::G_FLOATS : 0; }
+MCP_EXPORT int mcp_cross_grad_floats(int d) { return d == 64 ? GradShape<64>::G_FLOATS : d == 128 ? GradShape<128>::G_FLOATS : 0; }
 
 MCP_EXPORT size_t mcp_cross_grad_workspace_bytes(int b, int n1, int d) {
-    if (b <= 0 || n1 <= 0 || d != 64) return 0;
-    return (size_t)grad_grid((long long)b * n1, GradShape<64>::WAVES) * GradShape<64>::G_FLOATS * sizeof(float);
+    if (b <= 0 || n1 <= 0) return 0;
+    return d == 64 ? workspace_bytes<64>((long long)b * n1) : d == 128 ? workspace_bytes<128>((long long)b * n1) : 0;
 }
 
 MCP_EXPORT int mcp_cross_grad(int b, int n1, int n2, int d, int k, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
@@ -397,13 +476,16 @@ MCP_EXPORT int mcp_cross_grad(int b, int n1, int n2, int d, int k, const float *
                               void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n1 > 0 && n2 > 0 && xyz1 && xyz2 && points1 && points2 && idx && wpos && bpos && wmlp && bmlp && grad_out && grad_xyz1 &&
                    grad_dir && grad_points1 && grad_rows && grad_weights && workspace);
-    if (k != KNB || d != 64) return MCP_ERR_UNSUPPORTED;
-    if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)grad_out) | ((uintptr_t)grad_rows)) & 15) return MCP_ERR_BAD_ARG;
+    if (k != KNB || (d != 64 && d != 128)) return MCP_ERR_UNSUPPORTED;
+    if ((((uintptr_t)points1) | ((uintptr_t)points2) | ((uintptr_t)grad_out) | ((uintptr_t)grad_rows) | ((uintptr_t)workspace)) & 15) return MCP_ERR_BAD_ARG;
     if (workspace_bytes < mcp_cross_grad_workspace_bytes(b, n1, d)) return MCP_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)b * n1;
     mcp_prof_begin(MCP_KERNEL_CROSS, s);
-    const int rc = launch_cross_grad<64>((long long)b * n1, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, wpos, bpos, wmlp, bmlp, grad_out, grad_xyz1,
-                                         grad_dir, grad_points1, grad_rows, grad_weights, static_cast<float *>(workspace), s);
+    const int rc = d == 64 ? launch_cross_grad<64>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, wpos, bpos, wmlp, bmlp, grad_out, grad_xyz1,
+                                                   grad_dir, grad_points1, grad_rows, grad_weights, workspace, s)
+                           : launch_cross_grad<128>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, wpos, bpos, wmlp, bmlp, grad_out, grad_xyz1,
+                                                    grad_dir, grad_points1, grad_rows, grad_weights, workspace, s);
     mcp_prof_end(MCP_KERNEL_CROSS, s);
     return rc;
 }

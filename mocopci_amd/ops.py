@@ -138,7 +138,7 @@ class _PointConvAggFn(torch.autograd.Function):
 
 
 class _CrossFn(torch.autograd.Function):
-    """mcp_cross_volume with its hand-written backward (mcp_cross_grad, D = 64): recompute inside the backward kernel, the
+    """mcp_cross_volume with its hand-written backward (mcp_cross_grad, D = 64 / 128): recompute inside the backward kernel, the
     per-neighbour gradients through the deterministic segmented scatter (one sort serves both), weight gradients fixed-order sums."""
 
     @staticmethod

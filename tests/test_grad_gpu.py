@@ -5,6 +5,7 @@ restatement of the layer (float32, plain indexing), and one step of the referenc
 compared end to end."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 from mocopci_amd import ops, synth, training
 from oracle import pointset as orc
@@ -108,6 +109,18 @@ def test_fusion_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bi
           rnd(137, 128, scale=0.1)]
     g = rnd(138, 3, 1501, 3).to(DEV)
     names = ["p1", "p2", "w1", "b1", "w2", "b2", "w3", "b3"]
+    # The channel that holds a neighbour's maximum is decided by last bits when two channels are within rounding of each other
+    # (see the cross test): points with such a neighbour -- found in float64 -- get a zero upstream gradient.
+    whole = torch.cat(halves, dim=-1).long()
+    nb64 = p2.double()[torch.arange(3, device=DEV).view(3, 1, 1), whole]
+    r64 = nb64 - p1.double().unsqueeze(2)
+    x64 = torch.cat([r64, r64.norm(dim=-1, keepdim=True)], dim=-1)
+    for wi, bi_ in ((ws[0], ws[1]), (ws[2], ws[3]), (ws[4], ws[5])):
+        x64 = torch.relu(x64 @ wi.double().to(DEV).T + bi_.double().to(DEV))
+    top2 = x64.topk(2, dim=-1).values
+    clear = ((top2[..., 0] - top2[..., 1]) > 1e-4 * (1.0 + top2[..., 0])).all(dim=-1)
+    assert float(clear.float().mean()) > 0.9
+    g = g * clear.unsqueeze(-1).float()
 
     def grads(fn):
         leaves = [t.detach().clone().to(DEV).requires_grad_(True) for t in (p1, p2, *ws)]
@@ -123,24 +136,39 @@ def test_fusion_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bi
         assert err <= 2e-4 * scale + 2e-5, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
 
 
-def test_cross_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bit():
-    """mcp_cross_grad (D = 64) against autograd over the unfused layer (grad.cross_twin) on the device: the neighbour list as the two
+@pytest.mark.parametrize("d", [64, 128])
+def test_cross_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for_bit(d):
+    """mcp_cross_grad (D = 64; D = 128 with its three workgroup roles) against autograd over the unfused layer (grad.cross_twin) on the device: the neighbour list as the two
     searches' 16 + 16 halves -- which overlap, so equal maxima between list positions are the common case and the kernel's
     lowest-position rule must give the same total as autograd's choice -- n1 != n2, a ragged last workgroup; two runs, same bits."""
     from mocopci_amd import grad
     be = ops.backend()
-    n1, n2, d = 1237, 1500, 64
+    n1, n2 = 1237, 1500
     xyz1, xyz2 = cloud(140, 3, n1).to(DEV), cloud(141, 3, n2).to(DEV)
     f1, f2 = rnd(142, 3, n1, d).to(DEV), rnd(143, 3, n2, d).to(DEV)
     halves = (be.knn(xyz1, xyz2, 16), be.knn(xyz1, xyz2, 16))           # identical halves: every maximum is tied between two positions
     w = [rnd(144, d, 3, scale=0.3), rnd(145, d, scale=0.1), rnd(146, d, d, scale=d ** -0.5), rnd(147, d, scale=0.1)]
-    g = rnd(148, 3, n1, d).to(DEV)
+    g0 = rnd(148, 3, n1, d).to(DEV)
     names = ["xyz1", "xyz2", "points1", "points2", "wpos", "bpos", "wmlp", "bmlp"]
 
     def grads(fn, idx):
         leaves = [t.detach().clone().to(DEV).requires_grad_(True) for t in (xyz1, xyz2, f1, f2, *w)]
         return torch.autograd.grad(fn(*leaves[:4], idx, *leaves[4:]), leaves, g)
+    g = None
+    bi = torch.arange(3, device=DEV).view(3, 1, 1)
     for idx in (halves, be.knn(xyz1, xyz2, 32)):                        # ... and one (B,N1,32) list of distinct neighbours
+        # Which neighbour holds a channel's maximum is decided by z's last bits when two DISTINCT neighbours are within rounding of
+        # each other, and the kernel's z (its forward's bits) and torch's differ there: either choice is a valid subgradient, but
+        # the two gradients then differ by O(1) in that (point, channel); the same holds where a value sits on a LeakyReLU kink.
+        # Those pairs -- found in float64 -- get a zero upstream gradient, so the comparison stays strict everywhere else.
+        uniq = (idx[0] if isinstance(idx, tuple) else idx).long()
+        wd = [t.double().to(DEV) for t in w]
+        u64 = f2.double()[bi, uniq] + f1.double().unsqueeze(2) + (xyz2.double()[bi, uniq] - xyz1.double().unsqueeze(2)) @ wd[0].T + wd[1]
+        top2 = (F.leaky_relu(u64, 0.1) @ wd[2].T + wd[3]).topk(2, dim=2).values
+        clear = ((top2[:, :, 0] - top2[:, :, 1]) > 1e-4 * (1.0 + top2[:, :, 0].abs())) & (top2[:, :, 0].abs() > 1e-5)   # ... or sits on LeakyReLU's kink
+        clear &= (u64.abs().amin(dim=(2, 3)) > 1e-5).unsqueeze(-1)        # a point with some u_j[k] on the kink: LeakyReLU'(u) is 1 or 0.1 by rounding
+        g = g0 * clear.float()
+        assert float(clear.float().mean()) > 0.9
         hip = grads(be.cross_layer, idx)
         again = grads(be.cross_layer, idx)
         want = grads(lambda a, b, c, e, i, *ww: grad.cross_twin(be.group_rows, a, b, c, e, i, *ww), idx)
