@@ -234,6 +234,20 @@ int mcp_fusion_grad(int b, int n, int nb, const float *p1, const float *p2, cons
                     const float *w2, const float *b2, const float *w3, const float *b3, const float *grad_out, float *grad_p1, float *grad_nb,
                     float *grad_weights, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
 
+/* The fusion layer in net.train() mode (train.py:130): its three Conv2d + BatchNorm2d + ReLU layers (mocopci.py:749-755, :810-816)
+ * normalise with the statistics of the batch they are given -- one call here = one reference call = one set of statistics over
+ * all b * n * 64 (point, neighbour) rows.  Arguments as mcp_fusion with the RAW conv weights (w, b), then
+ *   bn    mcp_fusion_bn_floats() = 1024 floats, per layer (64, 64, 128 channels) mean | rstd | gamma | beta: the caller fills gamma
+ *         and beta (the BatchNorm weight / bias), this call fills mean and rstd = 1 / sqrt(var + eps);
+ *   var   64 + 64 + 128 floats: the biased batch variances (the caller's running-estimate update scales them by n / (n - 1)).
+ * Four passes (statistics of layer 1, 2, 3, then the layer itself), nothing of size rows x channels is written.
+ * workspace: mcp_fusion_bn_workspace_bytes(b, n) bytes. */
+int mcp_fusion_bn_floats(void);
+size_t mcp_fusion_bn_workspace_bytes(int b, int n);
+int mcp_fusion_bn_forward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1,
+                          const float *w2, const float *b2, const float *w3, const float *b3, float eps, float *bn, float *var, float *out,
+                          void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+
 /* Cost-volume cross() after its neighbour searches (pointconv_util.py:750-781, :894-922, :1126-1161):
  * xyz1 (B,N1,3), xyz2 (B,N2,3), points1 (B,N1,D), points2 (B,N2,D) channel-last (16-byte aligned),
  * idx (B,N1,32) int32 into set 2 (16 feature-cosine + 16 xyz neighbours) -> out (B,N1,D) = max over the 32

@@ -414,6 +414,29 @@ class HipBackend:
         ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
         return _FusionFn.apply(self, ia.contiguous(), None if ib is None else ib.contiguous(), p1, p2, w1, b1, w2, b2, w3, b3)
 
+    def fusion_bn_forward(self, p1, p2, idx, conv, affine, eps):
+        """The fusion layer of ONE reference call on batch statistics (net.train(); mocopci.py:810-819 with nn.BatchNorm2d in training
+        mode): conv = (w1, b1, w2, b2, w3, b3) raw conv weights, affine = (gamma1, beta1, gamma2, beta2, gamma3, beta3).
+        -> out (B,N,3), bn (1024: per layer mean | rstd | gamma | beta), var (256: biased batch variances 64 | 64 | 128).  No autograd."""
+        lib = _lib.load()
+        p1, p2 = p1.contiguous(), p2.contiguous()
+        conv = [t.detach().contiguous() for t in conv]
+        B, N, _ = p1.shape
+        ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
+        bn = torch.empty((lib.mcp_fusion_bn_floats(),), dtype=torch.float32, device=p1.device)
+        at = 0
+        for c, (g, b) in zip((64, 64, 128), zip(affine[0::2], affine[1::2])):
+            bn[at + 2 * c:at + 3 * c] = g.detach()
+            bn[at + 3 * c:at + 4 * c] = b.detach()
+            at += 4 * c
+        var = torch.empty((256,), dtype=torch.float32, device=p1.device)
+        out = torch.empty((B, N, 3), dtype=torch.float32, device=p1.device)
+        need = lib.mcp_fusion_bn_workspace_bytes(B, N)
+        ws = torch.empty((need,), dtype=torch.uint8, device=p1.device)
+        _call("mcp_fusion_bn_forward", p1, B, N, 64, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib),
+              *[_lib.fptr(t) for t in conv], float(eps), _lib.fptr(bn), _lib.fptr(var), _lib.fptr(out), ws.data_ptr(), need)
+        return out, bn, var
+
     def _fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):
         p1, p2, w1, b1, w2, b2, w3, b3 = (t.contiguous() for t in (p1, p2, w1, b1, w2, b2, w3, b3))
         B, N, _ = p1.shape
