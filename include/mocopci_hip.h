@@ -248,6 +248,19 @@ int mcp_fusion_bn_forward(int b, int n, int nb, const float *p1, const float *p2
                           const float *w2, const float *b2, const float *w3, const float *b3, float eps, float *bn, float *var, float *out,
                           void *workspace, size_t workspace_bytes, mcp_stream_t stream);
 
+/* Backward of mcp_fusion_bn_forward (one reference call; bn as that call left it).  grad_out (B,N,3).  The BatchNorm terms
+ * dz = (gamma / sigma)(dy' - mean(dy') - zhat mean(dy' zhat)) need sums over all rows between the layers: four passes, the layer
+ * re-evaluated in each as far as it is needed; dy2' and dy1' (rows x 64) pass through caller-provided scratch.  Scratch, rows = b n 64:
+ * row_c (rows int32), row_dy, row_a (rows floats), dy2, dy1 (rows x 64 floats, 16-byte aligned).  Writes grad_p1 (B,N,3), grad_nb (B,N,64,3)
+ * (scattered into dL/dp2 by the caller, as for mcp_fusion_grad), grad_weights (12800 floats in mcp_fusion_grad's layout; the conv
+ * biases' entries are 0: a bias in front of a batch-statistics BatchNorm has no gradient) and grad_affine (512 floats: dgamma1 |
+ * dbeta1 | dgamma2 | dbeta2 | dgamma3 | dbeta3).  All sums in fixed orders.  workspace: mcp_fusion_bn_grad_workspace_bytes(b, n). */
+size_t mcp_fusion_bn_grad_workspace_bytes(int b, int n);
+int mcp_fusion_bn_backward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1,
+                           const float *w2, const float *b2, const float *w3, const float *b3, const float *bn, const float *grad_out, int *row_c,
+                           float *row_dy, float *row_a, float *dy2, float *dy1, float *grad_p1, float *grad_nb, float *grad_weights,
+                           float *grad_affine, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+
 /* Cost-volume cross() after its neighbour searches (pointconv_util.py:750-781, :894-922, :1126-1161):
  * xyz1 (B,N1,3), xyz2 (B,N2,3), points1 (B,N1,D), points2 (B,N2,D) channel-last (16-byte aligned),
  * idx (B,N1,32) int32 into set 2 (16 feature-cosine + 16 xyz neighbours) -> out (B,N1,D) = max over the 32

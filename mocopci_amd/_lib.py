@@ -55,6 +55,8 @@ SIGNATURES = {
     "mcp_fusion_bn_floats": [],
     "mcp_fusion_bn_workspace_bytes": [_i, _i],
     "mcp_fusion_bn_forward": [_i, _i, _i] + [_p] * 10 + [_f] + [_p] * 4 + [ctypes.c_size_t, _p],
+    "mcp_fusion_bn_grad_workspace_bytes": [_i, _i],
+    "mcp_fusion_bn_backward": [_i, _i, _i] + [_p] * 22 + [ctypes.c_size_t, _p],
     "mcp_cross_packed_floats": [_i],
     "mcp_cross_pack": [_i, _p, _p, _p, _p, _p, _p],
     "mcp_cross_volume": [_i] * 5 + [_p] * 7 + [_i, _p, _p, _p],
@@ -89,7 +91,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": ctypes.c_size_t, "mcp_fusion_grad_workspace_bytes": ctypes.c_size_t,
              "mcp_cross_grad_workspace_bytes": ctypes.c_size_t, "mcp_pointconv_agg_grad_workspace_bytes": ctypes.c_size_t,
-             "mcp_fusion_bn_workspace_bytes": ctypes.c_size_t}
+             "mcp_fusion_bn_workspace_bytes": ctypes.c_size_t, "mcp_fusion_bn_grad_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

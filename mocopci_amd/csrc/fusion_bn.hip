@@ -280,6 +280,727 @@ int launch_fwd(long long total, int n, const float *p1, const float *p2, const i
     return mcp_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward passes
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_weights_transposed(uint4 *dst, const float *__restrict__ w, int m_total, int k_total, int first, int stride) {
+    const int ksteps = k_total / 16, out_tiles = m_total / 32;  // image of A[m][k] = w[k * m_total + m]
+    for (int e = first; e < out_tiles * ksteps * 64; e += stride) {
+        const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w[(size_t)(32 * (s >> 1) + mcp_chan_of(8 * (s & 1) + i, lane >> 5)) * m_total + 32 * t + (lane & 31)];
+        const McpSplit3 sp = mcp_split8(v);
+        uint4 *o = dst + (size_t)(t * ksteps + s) * 3 * 64 + lane;
+        o[0] = sp.p1;
+        o[64] = sp.p2;
+        o[128] = sp.p3;
+    }
+}
+__global__ __launch_bounds__(256) void transposed_image_kernel(uint4 *dst, const float *__restrict__ w, int m_total, int k_total) {
+    split_weights_transposed(dst, w, m_total, k_total, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+__device__ __forceinline__ void read8(const float *row, float *v) {
+    const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ float sum8(const float *v) { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
+// one accumulator-layout tile (32 channels x 32 neighbours) into rows 0..31 of a tile buffer: row = channel, column = neighbour
+__device__ __forceinline__ void write_tile(float *tb, const f32x16 &v, int col, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tb[chan_of(r, h) * TS + col] = v[r];
+}
+__device__ __forceinline__ f32x16 mfma_split6(const McpSplit3 &a, const McpSplit3 &b, f32x16 acc) {
+    acc = mcp_mfma_bf16(a.p3, b.p1, acc);
+    acc = mcp_mfma_bf16(a.p1, b.p3, acc);
+    acc = mcp_mfma_bf16(a.p2, b.p2, acc);
+    acc = mcp_mfma_bf16(a.p2, b.p1, acc);
+    acc = mcp_mfma_bf16(a.p1, b.p2, acc);
+    acc = mcp_mfma_bf16(a.p1, b.p1, acc);
+    return acc;
+}
+// per-channel constants of dz = a dy' - c1 - zhat c2 in accumulator order: a = gamma rstd, c1 = a sum(dy') / R, c2 = a sum(dy' zhat) / R
+__device__ __forceinline__ void stage_dz_consts(float *dst, const float *__restrict__ bn_layer, const float *__restrict__ sums, int c, float inv_rows, int tid,
+                                                int threads) {
+    for (int e = tid; e < c; e += threads) {
+        const int ch = acc_to_channel(e);
+        const float a = bn_layer[2 * c + ch] * bn_layer[c + ch];
+        dst[e] = a;
+        dst[c + e] = a * (sums[ch] * inv_rows);
+        dst[2 * c + e] = a * (sums[c + ch] * inv_rows);
+    }
+}
+template <int C>
+__device__ __forceinline__ void dz_tile(const float *at, const f32x16 &dy, const f32x16 &zhat, f32x16 &dz) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dz[r] = __builtin_fmaf(-zhat[r], at[2 * C + r], __builtin_fmaf(at[r], dy[r], -at[C + r]));
+}
+// rows of a (rows, 64) fp32 array in accumulator layout: channels 32 t + 8 q + 4 h + (0..3) = registers 4 q .. 4 q + 3 of tile t
+__device__ __forceinline__ void load_row64(const float *row, int h, f32x16 *v) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = reinterpret_cast<const float4 *>(row)[8 * t + 2 * q + h];
+            v[t][4 * q + 0] = a.x; v[t][4 * q + 1] = a.y; v[t][4 * q + 2] = a.z; v[t][4 * q + 3] = a.w;
+        }
+}
+__device__ __forceinline__ void store_row64(float *row, int h, const f32x16 *v) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            reinterpret_cast<float4 *>(row)[8 * t + 2 * q + h] = make_float4(v[t][4 * q + 0], v[t][4 * q + 1], v[t][4 * q + 2], v[t][4 * q + 3]);
+}
+// sum over the neighbours of dy' and dy' zhat with lane = channel (both tensors through the transposition tile): 4 registers of
+// accumulators instead of 64.  sums[mt] / sumz[mt]: channel 32 mt + col, the two lane halves hold the two 8-neighbour groups.
+__device__ __forceinline__ void channel_sums(float *tb, const f32x16 *dy, const f32x16 *zhat, int col, int h, float *sums, float *sumz) {
+    float dyv[2][2][8];
+    __builtin_amdgcn_wave_barrier();
+    write_tile(tb, dy[0], col, h);
+    write_tile(tb + 32 * TS, dy[1], col, h);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, dyv[mt][ks]);
+            sums[mt] += sum8(dyv[mt][ks]);
+        }
+    __builtin_amdgcn_wave_barrier();
+    write_tile(tb, zhat[0], col, h);
+    write_tile(tb + 32 * TS, zhat[1], col, h);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float zv[8];
+            read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, zv);
+            float a = dyv[mt][ks][0] * zv[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) a = __builtin_fmaf(dyv[mt][ks][i], zv[i], a);
+            sumz[mt] += a;
+        }
+}
+
+// ---- B1: the forward with arg-max channel, softmax, ds -> per-row (c*, dy3' at c*, softmax weight), sums of dy3' and dy3' zhat3 ----
+constexpr int B1_SCR = 96;  // per wave: c* [32] | dy3' [32] | dy3' zhat3 [32]
+__global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b1_kernel(long long total, int n, const float *__restrict__ p1, const float *__restrict__ p2,
+                                                                  const int *__restrict__ idx, const int *__restrict__ idx2,
+                                                                  const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                  const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                  const float *__restrict__ w3, const float *__restrict__ b3,
+                                                                  const float *__restrict__ bn, const float *__restrict__ gout, int *__restrict__ row_c,
+                                                                  float *__restrict__ row_dy, float *__restrict__ row_a, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4 *w2s = reinterpret_cast<uint4 *>(lds + L_F32);
+    uint4 *w3s = w2s + W2_U4;
+    const int tid = threadIdx.x;
+    stage_f32(lds, w1, b1, b2, b3, bn, 3, tid, 64 * WAVES);
+    mcp_split_weights(w2s, w2, C1, 2, tid, 64 * WAVES);
+    mcp_split_weights(w3s, w3, C2, 4, tid, 64 * WAVES);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    float *scr = reinterpret_cast<float *>(w3s + W3_U4) + wave * B1_SCR;
+    int *csb = reinterpret_cast<int *>(scr);
+    float *dzb = scr + 32, *ezb = scr + 64;
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};  // lane = channel 32 mt + col
+
+    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+        const long long bb = mcp_div(p, n, mcp_fits32(total));
+        const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
+        const float gx = gout[p * 3 + 0], gy = gout[p * 3 + 1], gz = gout[p * 3 + 2];
+        float score[2], zstar[2], nbx[2], nby[2], nbz[2];
+        int cstar[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int id = idx2 ? (ct ? idx2 : idx)[p * 32 + col] : idx[p * NB + 32 * ct + col];
+            const float *q = p2 + ((long long)bb * n + id) * 3;
+            const float x = q[0], y = q[1], z = q[2];
+            nbx[ct] = x; nby[ct] = y; nbz[ct] = z;
+            const float rx = x - cx, ry = y - cy, rz = z - cz;
+            const float dist = sqrtf((rx * rx + ry * ry) + rz * rz);
+            const float in0 = h ? ry : rx, in1 = h ? dist : rz;
+            McpSplit3 x1[4], x2[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x16 z1 = layer1_tile<false>(lds, t, h, lane, in0, in1);
+                f32x16 zh, v;
+                bn_tile<C1>(lds + L_BN1 + (t * 2 + h) * 16, z1, zh, v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                x1[2 * t + 0] = mcp_split_kstep(v, 0);
+                x1[2 * t + 1] = mcp_split_kstep(v, 1);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 z2 = bias_tile<false>(lds, L_B2 + (t * 2 + h) * 16);
+                z2 = mcp_tile_split<4>(w2s + (size_t)t * 4 * 3 * 64 + lane, x1, z2);
+                f32x16 zh, v;
+                bn_tile<C2>(lds + L_BN2 + (t * 2 + h) * 16, z2, zh, v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                x2[2 * t + 0] = mcp_split_kstep(v, 0);
+                x2[2 * t + 1] = mcp_split_kstep(v, 1);
+            }
+            float m = 0.f, zb = 0.f;
+            int mr = 0;
+#pragma unroll 1
+            for (int t = 0; t < 4; ++t) {
+                f32x16 z3 = bias_tile<false>(lds, L_B3 + (t * 2 + h) * 16);
+                z3 = mcp_tile_split<4>(w3s + (size_t)t * 4 * 3 * 64 + lane, x2, z3);
+                f32x16 zh, v;
+                bn_tile<C3>(lds + L_BN3 + (t * 2 + h) * 16, z3, zh, v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool up = v[r] > m;
+                    m = up ? v[r] : m;
+                    zb = up ? zh[r] : zb;
+                    mr = up ? 16 * t + r : mr;
+                }
+            }
+            const int mc = 32 * (mr >> 4) + chan_of(mr & 15, h);
+            const float om = __shfl_xor(m, 32), oz = __shfl_xor(zb, 32);
+            const int oc = __shfl_xor(mc, 32);
+            const bool other = om > m || (om == m && oc < mc);
+            score[ct] = other ? om : m;
+            zstar[ct] = other ? oz : zb;
+            cstar[ct] = other ? oc : mc;
+        }
+        const float mx = wave_max(fmaxf(score[0], score[1]));
+        const float e0 = expf(score[0] - mx), e1 = expf(score[1] - mx);
+        const float den = 0.5f * wave_sum(e0 + e1);  // every neighbour sits in both lane halves
+        const float a0 = e0 / den, a1 = e1 / den;
+        const float da0 = (gx * nbx[0] + gy * nby[0]) + gz * nbz[0], da1 = (gx * nbx[1] + gy * nby[1]) + gz * nbz[1];
+        const float sdot = 0.5f * wave_sum(a0 * da0 + a1 * da1);
+        const float dy[2] = {score[0] > 0.f ? a0 * (da0 - sdot) : 0.f, score[1] > 0.f ? a1 * (da1 - sdot) : 0.f};
+        const float aw[2] = {a0, a1};
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            __builtin_amdgcn_wave_barrier();
+            if (h == 0) {
+                const long long row = p * NB + 32 * ct + col;
+                row_c[row] = cstar[ct];
+                row_dy[row] = dy[ct];
+                row_a[row] = aw[ct];
+                csb[col] = cstar[ct];
+                dzb[col] = dy[ct];
+                ezb[col] = dy[ct] * zstar[ct];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int j0 = 16 * ks + 8 * h;
+                const int4 ca = reinterpret_cast<const int4 *>(csb + j0)[0], cb = reinterpret_cast<const int4 *>(csb + j0)[1];
+                const int cs8[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+                float dz8[8], ez8[8];
+                read8(dzb + j0, dz8);
+                read8(ezb + j0, ez8);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int c = 32 * mt + col;
+                    float s = 0.f, g = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        s += cs8[i] == c ? dz8[i] : 0.f;
+                        g += cs8[i] == c ? ez8[i] : 0.f;
+                    }
+                    sb[mt] += s;
+                    sg[mt] += g;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float *red = lds;  // [WAVES][256]: sum dy3' (128) | sum dy3' zhat3 (128), natural channel order
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const float a = sb[mt] + __shfl_xor(sb[mt], 32), b = sg[mt] + __shfl_xor(sg[mt], 32);
+        if (h == 0) {
+            red[wave * 256 + 32 * mt + col] = a;
+            red[wave * 256 + 128 + 32 * mt + col] = b;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        float v = red[tid];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) v += red[w * 256 + tid];
+        partial[(size_t)blockIdx.x * 256 + tid] = v;
+    }
+}
+
+// ---- B2: dz3 (dense), dW3 += dz3 . y2^T, dh2 = W3^T dz3 -> dy2' (stored), sums of dy2' and dy2' zhat2 ----
+constexpr int B2_L_DZ = L_F32, B2_F32 = L_F32 + 3 * C3;                  // + a | c1 | c2 of layer 3 (accumulator order)
+constexpr int B2_SCR = 64 * TS + 32 * TS;                                // per wave: tile [64][TS] (y2^T, then the sums) | tile [32][TS] (a dz3 tile)
+constexpr int B2_G = C3 * C2 + 2 * C2;                                   // the workgroup's vector: dW3 (128,64) | sum dy2' | sum dy2' zhat2
+constexpr size_t B2_LDS = (size_t)B2_F32 * 4 + (size_t)(W2_U4 + W3_U4) * 16 + (size_t)WAVES * B2_SCR * 4;
+static_assert(B2_LDS <= 160 * 1024, "LDS budget");
+__global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b2_kernel(long long total, int n, const float *__restrict__ p1, const float *__restrict__ p2,
+                                                                  const int *__restrict__ idx, const int *__restrict__ idx2,
+                                                                  const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                  const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                  const float *__restrict__ w3, const float *__restrict__ b3,
+                                                                  const float *__restrict__ bn, const float *__restrict__ sums3, float inv_rows,
+                                                                  const uint4 *__restrict__ w3t, const int *__restrict__ row_c,
+                                                                  const float *__restrict__ row_dy, float *__restrict__ dy2, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4 *w2s = reinterpret_cast<uint4 *>(lds + B2_F32);
+    uint4 *w3s = w2s + W2_U4;
+    const int tid = threadIdx.x;
+    stage_f32(lds, w1, b1, b2, b3, bn, 3, tid, 64 * WAVES);
+    stage_dz_consts(lds + B2_L_DZ, bn + BN_L3, sums3, C3, inv_rows, tid, 64 * WAVES);
+    mcp_split_weights(w2s, w2, C1, 2, tid, 64 * WAVES);
+    mcp_split_weights(w3s, w3, C2, 4, tid, 64 * WAVES);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    float *tb = reinterpret_cast<float *>(w3s + W3_U4) + wave * B2_SCR;
+    float *tz = tb + 64 * TS;
+
+    f32x16 dW3a[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dW3a[a][b][r] = 0.f;
+    float s2[2] = {0.f, 0.f}, g2[2] = {0.f, 0.f};
+
+    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+        const long long bb = mcp_div(p, n, mcp_fits32(total));
+        const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
+#pragma unroll 1
+        for (int ct = 0; ct < 2; ++ct) {
+            const int id = idx2 ? (ct ? idx2 : idx)[p * 32 + col] : idx[p * NB + 32 * ct + col];
+            const long long row = p * NB + 32 * ct + col;
+            const int cst = row_c[row];
+            const float dys = row_dy[row];
+            const float *q = p2 + ((long long)bb * n + id) * 3;
+            const float rx = q[0] - cx, ry = q[1] - cy, rz = q[2] - cz;
+            const float dist = sqrtf((rx * rx + ry * ry) + rz * rz);
+            const float in0 = h ? ry : rx, in1 = h ? dist : rz;
+            uint32_t live2 = 0u;  // bit 16 t + r: y2 > 0 in register r of tile t
+            McpSplit3 x2[4], bs[2][2];
+            {
+                f32x16 zh2[2];
+                McpSplit3 x1[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x16 z1 = layer1_tile<false>(lds, t, h, lane, in0, in1);
+                    f32x16 zh, v;
+                    bn_tile<C1>(lds + L_BN1 + (t * 2 + h) * 16, z1, zh, v);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                    x1[2 * t + 0] = mcp_split_kstep(v, 0);
+                    x1[2 * t + 1] = mcp_split_kstep(v, 1);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x16 z2 = bias_tile<false>(lds, L_B2 + (t * 2 + h) * 16);
+                    z2 = mcp_tile_split<4>(w2s + (size_t)t * 4 * 3 * 64 + lane, x1, z2);
+                    f32x16 v;
+                    bn_tile<C2>(lds + L_BN2 + (t * 2 + h) * 16, z2, zh2[t], v);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        live2 |= v[r] > 0.f ? 1u << (16 * t + r) : 0u;
+                        v[r] = fmaxf(v[r], 0.f);
+                    }
+                    x2[2 * t + 0] = mcp_split_kstep(v, 0);
+                    x2[2 * t + 1] = mcp_split_kstep(v, 1);
+                    write_tile(tb + 32 * t * TS, v, col, h);  // y2^T: the B operand of dW3
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        float v[8];
+                        read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
+                        bs[nt][ks] = mcp_split8(v);
+                    }
+                __builtin_amdgcn_wave_barrier();
+                write_tile(tb, zh2[0], col, h);  // zhat2^T stays in the tile until the sums at the end of the half
+                write_tile(tb + 32 * TS, zh2[1], col, h);
+            }
+            f32x16 dh2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh2[t][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                __builtin_amdgcn_sched_barrier(0);  // a tile's loads are not hoisted above the previous tile (registers)
+                f32x16 z3 = bias_tile<false>(lds, L_B3 + (t * 2 + h) * 16);
+                z3 = mcp_tile_split<4>(w3s + (size_t)t * 4 * 3 * 64 + lane, x2, z3);
+                f32x16 zh, v, dy, dz;
+                bn_tile<C3>(lds + L_BN3 + (t * 2 + h) * 16, z3, zh, v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dy[r] = (32 * t + chan_of(r, h)) == cst ? dys : 0.f;
+                dz_tile<C3>(lds + B2_L_DZ + (t * 2 + h) * 16, dy, zh, dz);
+                __builtin_amdgcn_wave_barrier();
+                write_tile(tz, dz, col, h);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v8[8];
+                    read8(tz + col * TS + 16 * ks + 8 * h, v8);
+                    const McpSplit3 as = mcp_split8(v8);
+                    dW3a[t][0] = mfma_split6(as, bs[0][ks], dW3a[t][0]);
+                    dW3a[t][1] = mfma_split6(as, bs[1][ks], dW3a[t][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const McpSplit3 z0 = mcp_split_kstep(dz, 0), z1s = mcp_split_kstep(dz, 1);
+#pragma unroll
+                for (int to = 0; to < 2; ++to) {
+                    const uint4 *wk = w3t + ((size_t)to * 8 + 2 * t) * 3 * 64 + lane;
+                    dh2[to] = mcp_mfma_split(wk, z0, dh2[to]);
+                    dh2[to] = mcp_mfma_split(wk + 3 * 64, z1s, dh2[to]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // dy2' = dh2 [y2 > 0]; its sums over the neighbours with lane = channel (dy2' through the small tile, zhat2^T is in the large one)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh2[t][r] = (live2 >> (16 * t + r)) & 1u ? dh2[t][r] : 0.f;
+            store_row64(dy2 + row * C2, h, dh2);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                __builtin_amdgcn_wave_barrier();
+                write_tile(tz, dh2[mt], col, h);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float dv[8], zv[8];
+                    read8(tz + col * TS + 16 * ks + 8 * h, dv);
+                    read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, zv);
+                    s2[mt] += sum8(dv);
+                    float a = dv[0] * zv[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) a = __builtin_fmaf(dv[i], zv[i], a);
+                    g2[mt] += a;
+                }
+            }
+        }
+    }
+    // ---- the workgroup's vector: waves in wave order through LDS ----
+    __syncthreads();
+    float *red = lds;
+    for (int e = tid; e < B2_G; e += 64 * WAVES) red[e] = 0.f;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(32 * mt + chan_of(r, h)) * C2 + 32 * nt + col] += dW3a[mt][nt][r];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float a = s2[mt] + __shfl_xor(s2[mt], 32), b = g2[mt] + __shfl_xor(g2[mt], 32);
+                if (h == 0) {
+                    red[C3 * C2 + 32 * mt + col] += a;
+                    red[C3 * C2 + C2 + 32 * mt + col] += b;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < B2_G; e += 64 * WAVES) partial[(size_t)blockIdx.x * B2_G + e] = red[e];
+}
+
+// ---- B3: dz2, dW2 += dz2 . y1^T, dh1 = W2^T dz2 -> dy1' (stored), sums of dy1' and dy1' zhat1 ----
+constexpr int B3_L_DZ = L_F32, B3_F32 = L_F32 + 3 * C2;
+constexpr int B3_SCR = 64 * TS;
+constexpr int B3_G = C2 * C1 + 2 * C1;  // dW2 (64,64) | sum dy1' | sum dy1' zhat1
+constexpr size_t B3_LDS = (size_t)B3_F32 * 4 + (size_t)(2 * W2_U4) * 16 + (size_t)WAVES * B3_SCR * 4;
+__global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b3_kernel(long long total, int n, const float *__restrict__ p1, const float *__restrict__ p2,
+                                                                  const int *__restrict__ idx, const int *__restrict__ idx2,
+                                                                  const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                  const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                  const float *__restrict__ b3, const float *__restrict__ bn,
+                                                                  const float *__restrict__ sums2, float inv_rows, const float *__restrict__ dy2,
+                                                                  float *__restrict__ dy1, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4 *w2s = reinterpret_cast<uint4 *>(lds + B3_F32);
+    uint4 *w2ts = w2s + W2_U4;
+    const int tid = threadIdx.x;
+    stage_f32(lds, w1, b1, b2, b3, bn, 2, tid, 64 * WAVES);
+    stage_dz_consts(lds + B3_L_DZ, bn + BN_L2, sums2, C2, inv_rows, tid, 64 * WAVES);
+    mcp_split_weights(w2s, w2, C1, 2, tid, 64 * WAVES);
+    split_weights_transposed(w2ts, w2, C1, C2, tid, 64 * WAVES);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    float *tb = reinterpret_cast<float *>(w2ts + W2_U4) + wave * B3_SCR;
+
+    f32x16 dW2a[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dW2a[a][b][r] = 0.f;
+    float s1[2] = {0.f, 0.f}, g1[2] = {0.f, 0.f};
+
+    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+        const long long bb = mcp_div(p, n, mcp_fits32(total));
+        const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
+#pragma unroll 1
+        for (int ct = 0; ct < 2; ++ct) {
+            const int id = idx2 ? (ct ? idx2 : idx)[p * 32 + col] : idx[p * NB + 32 * ct + col];
+            const long long row = p * NB + 32 * ct + col;
+            const float *q = p2 + ((long long)bb * n + id) * 3;
+            const float rx = q[0] - cx, ry = q[1] - cy, rz = q[2] - cz;
+            const float dist = sqrtf((rx * rx + ry * ry) + rz * rz);
+            const float in0 = h ? ry : rx, in1 = h ? dist : rz;
+            f32x16 zh1[2], y1[2], dz2[2];
+            {
+                McpSplit3 x1[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x16 z1 = layer1_tile<false>(lds, t, h, lane, in0, in1);
+                    f32x16 v;
+                    bn_tile<C1>(lds + L_BN1 + (t * 2 + h) * 16, z1, zh1[t], v);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y1[t][r] = fmaxf(v[r], 0.f);
+                    x1[2 * t + 0] = mcp_split_kstep(y1[t], 0);
+                    x1[2 * t + 1] = mcp_split_kstep(y1[t], 1);
+                }
+                f32x16 dy[2];
+                load_row64(dy2 + row * C2, h, dy);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x16 z2 = bias_tile<false>(lds, L_B2 + (t * 2 + h) * 16);
+                    z2 = mcp_tile_split<4>(w2s + (size_t)t * 4 * 3 * 64 + lane, x1, z2);
+                    f32x16 zh, v;
+                    bn_tile<C2>(lds + L_BN2 + (t * 2 + h) * 16, z2, zh, v);
+                    dz_tile<C2>(lds + B3_L_DZ + (t * 2 + h) * 16, dy[t], zh, dz2[t]);
+                }
+            }
+            // dW2 += dz2 . y1^T
+            __builtin_amdgcn_wave_barrier();
+            write_tile(tb, dz2[0], col, h);
+            write_tile(tb + 32 * TS, dz2[1], col, h);
+            __builtin_amdgcn_wave_barrier();
+            McpSplit3 as[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[8];
+                    read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                    as[mt][ks] = mcp_split8(v);
+                }
+            __builtin_amdgcn_wave_barrier();
+            write_tile(tb, y1[0], col, h);
+            write_tile(tb + 32 * TS, y1[1], col, h);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[8];
+                    read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
+                    const McpSplit3 bsp = mcp_split8(v);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) dW2a[mt][nt] = mfma_split6(as[mt][ks], bsp, dW2a[mt][nt]);
+                }
+            // dh1 = W2^T dz2; dy1' = dh1 [y1 > 0]
+            f32x16 dh1[2];
+            {
+                McpSplit3 xs[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    xs[2 * t + 0] = mcp_split_kstep(dz2[t], 0);
+                    xs[2 * t + 1] = mcp_split_kstep(dz2[t], 1);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    acc = mcp_tile_split<4>(w2ts + (size_t)t * 4 * 3 * 64 + lane, xs, acc);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dh1[t][r] = y1[t][r] > 0.f ? acc[r] : 0.f;
+                }
+            }
+            store_row64(dy1 + row * C1, h, dh1);
+            channel_sums(tb, dh1, zh1, col, h, s1, g1);
+        }
+    }
+    __syncthreads();
+    float *red = lds;
+    for (int e = tid; e < B3_G; e += 64 * WAVES) red[e] = 0.f;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(32 * mt + chan_of(r, h)) * C1 + 32 * nt + col] += dW2a[mt][nt][r];
+                const float a = s1[mt] + __shfl_xor(s1[mt], 32), b = g1[mt] + __shfl_xor(g1[mt], 32);
+                if (h == 0) {
+                    red[C2 * C1 + 32 * mt + col] += a;
+                    red[C2 * C1 + C1 + 32 * mt + col] += b;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < B3_G; e += 64 * WAVES) partial[(size_t)blockIdx.x * B3_G + e] = red[e];
+}
+
+// ---- B4: dz1, dW1 += dz1 . x0^T, dx0 = W1^T dz1 -> d_nb, d_p1 ----
+constexpr int B4_L_DZ = L_F32, B4_L_W1R = L_F32 + 3 * C1, B4_F32 = B4_L_W1R + 256;
+constexpr int B4_SCR = 64 * TS + 128;  // per wave: tile | x0 [32][4]
+constexpr int B4_G = C1 * 4;           // dW1 (64,4)
+constexpr size_t B4_LDS = (size_t)B4_F32 * 4 + (size_t)WAVES * B4_SCR * 4;
+__global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b4_kernel(long long total, int n, const float *__restrict__ p1, const float *__restrict__ p2,
+                                                                  const int *__restrict__ idx, const int *__restrict__ idx2,
+                                                                  const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                  const float *__restrict__ b2, const float *__restrict__ b3,
+                                                                  const float *__restrict__ bn, const float *__restrict__ sums1, float inv_rows,
+                                                                  const float *__restrict__ dy1, const float *__restrict__ row_a,
+                                                                  const float *__restrict__ gout, float *__restrict__ d_p1, float *__restrict__ d_nb,
+                                                                  float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    stage_f32(lds, w1, b1, b2, b3, bn, 1, tid, 64 * WAVES);
+    stage_dz_consts(lds + B4_L_DZ, bn + BN_L1, sums1, C1, inv_rows, tid, 64 * WAVES);
+    for (int e = tid; e < 256; e += 64 * WAVES) {  // W1 rows in accumulator order, for dx0 = W1^T dz1
+        const int k = e & 3, r = (e >> 2) & 15, hh = (e >> 6) & 1, tt = e >> 7;
+        lds[B4_L_W1R + e] = w1[(32 * tt + chan_of(r, hh)) * 4 + k];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    float *tb = lds + B4_F32 + wave * B4_SCR;
+    float4 *x0b = reinterpret_cast<float4 *>(tb + 64 * TS);
+    float dW1a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+        const long long bb = mcp_div(p, n, mcp_fits32(total));
+        const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
+        const float gx = gout[p * 3 + 0], gy = gout[p * 3 + 1], gz = gout[p * 3 + 2];
+        float dcx = 0.f, dcy = 0.f, dcz = 0.f;
+#pragma unroll 1
+        for (int ct = 0; ct < 2; ++ct) {
+            const int id = idx2 ? (ct ? idx2 : idx)[p * 32 + col] : idx[p * NB + 32 * ct + col];
+            const long long row = p * NB + 32 * ct + col;
+            const float aw = row_a[row];
+            const float *q = p2 + ((long long)bb * n + id) * 3;
+            const float rx = q[0] - cx, ry = q[1] - cy, rz = q[2] - cz;
+            const float dist = sqrtf((rx * rx + ry * ry) + rz * rz);
+            const float in0 = h ? ry : rx, in1 = h ? dist : rz;
+            f32x16 dy[2], dz1[2];
+            load_row64(dy1 + row * C1, h, dy);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x16 z1 = layer1_tile<false>(lds, t, h, lane, in0, in1);
+                f32x16 zh, v;
+                bn_tile<C1>(lds + L_BN1 + (t * 2 + h) * 16, z1, zh, v);
+                dz_tile<C1>(lds + B4_L_DZ + (t * 2 + h) * 16, dy[t], zh, dz1[t]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            write_tile(tb, dz1[0], col, h);
+            write_tile(tb + 32 * TS, dz1[1], col, h);
+            if (h == 0) x0b[col] = make_float4(rx, ry, rz, dist);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[8];
+                    read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float4 xj = x0b[16 * ks + 8 * h + i];
+                        dW1a[mt][0] = __builtin_fmaf(v[i], xj.x, dW1a[mt][0]);
+                        dW1a[mt][1] = __builtin_fmaf(v[i], xj.y, dW1a[mt][1]);
+                        dW1a[mt][2] = __builtin_fmaf(v[i], xj.z, dW1a[mt][2]);
+                        dW1a[mt][3] = __builtin_fmaf(v[i], xj.w, dW1a[mt][3]);
+                    }
+                }
+            float dx0 = 0.f, dx1 = 0.f, dx2 = 0.f, dx3 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 w = reinterpret_cast<const float4 *>(lds + B4_L_W1R)[(t * 2 + h) * 16 + r];
+                    dx0 = __builtin_fmaf(w.x, dz1[t][r], dx0);
+                    dx1 = __builtin_fmaf(w.y, dz1[t][r], dx1);
+                    dx2 = __builtin_fmaf(w.z, dz1[t][r], dx2);
+                    dx3 = __builtin_fmaf(w.w, dz1[t][r], dx3);
+                }
+            dx0 += __shfl_xor(dx0, 32);
+            dx1 += __shfl_xor(dx1, 32);
+            dx2 += __shfl_xor(dx2, 32);
+            dx3 += __shfl_xor(dx3, 32);
+            const float sc = dist > 0.f ? dx3 / dist : 0.f;
+            const float drx = __builtin_fmaf(sc, rx, dx0), dry = __builtin_fmaf(sc, ry, dx1), drz = __builtin_fmaf(sc, rz, dx2);
+            if (h == 0) {
+                float *o = d_nb + row * 3;
+                o[0] = __builtin_fmaf(aw, gx, drx);
+                o[1] = __builtin_fmaf(aw, gy, dry);
+                o[2] = __builtin_fmaf(aw, gz, drz);
+            }
+            dcx += drx; dcy += dry; dcz += drz;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const float sx = wave_sum(dcx), sy = wave_sum(dcy), sz = wave_sum(dcz);
+        if (lane == 0) {
+            d_p1[p * 3 + 0] = -0.5f * sx;
+            d_p1[p * 3 + 1] = -0.5f * sy;
+            d_p1[p * 3 + 2] = -0.5f * sz;
+        }
+    }
+    __syncthreads();
+    float *red = lds;  // [WAVES][256]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v = dW1a[mt][k] + __shfl_xor(dW1a[mt][k], 32);
+            if (h == 0) red[wave * B4_G + (32 * mt + col) * 4 + k] = v;
+        }
+    __syncthreads();
+    if (tid < B4_G) {
+        float v = red[tid];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) v += red[w * B4_G + tid];
+        partial[(size_t)blockIdx.x * B4_G + tid] = v;
+    }
+}
+
+// out[e] = sum over the workgroups' partial vectors, in workgroup order
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ partial, int parts, int stride, int count, float *__restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    float s = 0.f;
+    for (int g = 0; g < parts; ++g) s += partial[(size_t)g * stride + e];
+    out[e] = s;
+}
+
+unsigned bwd_grid(long long total, int per_cu) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const long long want = (total + WAVES - 1) / WAVES, cap = (long long)per_cu * cus;
+    return (unsigned)(want < cap ? want : cap);
+}
+constexpr int W3T_U4 = 2 * 8 * 3 * 64;  // image of W3^T (M = 64, K = 128)
+// workspace (floats): partial vectors (the largest pass: B2) | sums3 (256) | sums2 (128) | sums1 (128) | the W3^T image
+size_t bwd_workspace_floats(long long total) {
+    const size_t parts = (size_t)bwd_grid(total, 2);  // >= every pass's grid
+    return parts * B2_G + 512 + (size_t)W3T_U4 * 4;
+}
+
 }  // namespace
 
 MCP_EXPORT int mcp_fusion_bn_floats(void) { return BN_FLOATS; }
@@ -316,4 +1037,84 @@ MCP_EXPORT int mcp_fusion_bn_forward(int b, int n, int nb, const float *p1, cons
     rc = launch_fwd<0>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, out, grid, s);
     mcp_prof_end(MCP_KERNEL_FUSION, s);
     return rc;
+}
+
+MCP_EXPORT size_t mcp_fusion_bn_grad_workspace_bytes(int b, int n) {
+    if (b <= 0 || n <= 0) return 0;
+    return bwd_workspace_floats((long long)b * n) * sizeof(float);
+}
+
+// The layer on batch statistics, backward (one reference call; bn as mcp_fusion_bn_forward left it).  grad_out (B,N,3).  Scratch the
+// caller provides: row_c (rows int32), row_dy, row_a (rows floats), dy2, dy1 (rows x 64 floats), rows = b * n * 64.  Writes grad_p1
+// (B,N,3), grad_nb (B,N,64,3) (for the caller's scatter into dL/dp2), grad_weights (12800 floats, mcp_fusion_grad's layout; the
+// conv-bias entries are 0: a bias in front of a batch-statistics BatchNorm has no gradient) and grad_affine (512 floats: per layer
+// dgamma | dbeta -- 64 | 64, 64 | 64, 128 | 128).
+MCP_EXPORT int mcp_fusion_bn_backward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1,
+                                      const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, const float *bn,
+                                      const float *grad_out, int *row_c, float *row_dy, float *row_a, float *dy2, float *dy1, float *grad_p1,
+                                      float *grad_nb, float *grad_weights, float *grad_affine, void *workspace, size_t workspace_bytes,
+                                      mcp_stream_t stream) {
+    MCP_CHECK_ARGS(b > 0 && n > 0 && p1 && p2 && idx && w1 && b1 && w2 && b2 && w3 && b3 && bn && grad_out && row_c && row_dy && row_a && dy2 && dy1 &&
+                   grad_p1 && grad_nb && grad_weights && grad_affine && workspace);
+    if (nb != NB) return MCP_ERR_UNSUPPORTED;
+    if ((((uintptr_t)dy2) | ((uintptr_t)dy1) | ((uintptr_t)workspace)) & 15) return MCP_ERR_BAD_ARG;
+    const long long total = (long long)b * n;
+    if (workspace_bytes < bwd_workspace_floats(total) * sizeof(float)) return MCP_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    float *ws = static_cast<float *>(workspace);
+    const size_t parts_cap = (size_t)bwd_grid(total, 2);
+    float *partial = ws, *sums3 = ws + parts_cap * B2_G, *sums2 = sums3 + 256, *sums1 = sums2 + 128;
+    uint4 *w3t = reinterpret_cast<uint4 *>(sums1 + 128);
+    const float inv_rows = (float)(1.0 / ((double)total * NB));
+    // grad_weights layout (mcp_fusion_grad): dW1 (64,4) | db1 | dW2 (64,64) | db2 | dW3 (128,64) | db3
+    constexpr int G_W1 = 0, G_W2 = 320, G_B2 = G_W2 + 4096, G_W3 = G_B2 + 64, G_B3 = G_W3 + 8192, G_FLOATS = G_B3 + 128;
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        const void *kerns[4] = {reinterpret_cast<const void *>(fusion_bn_b1_kernel), reinterpret_cast<const void *>(fusion_bn_b2_kernel),
+                                reinterpret_cast<const void *>(fusion_bn_b3_kernel), reinterpret_cast<const void *>(fusion_bn_b4_kernel)};
+        for (const void *k : kerns) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+        }
+        attr_once.done();
+    }
+    mcp_prof_begin(MCP_KERNEL_FUSION, s);
+    (void)hipMemsetAsync(grad_weights, 0, G_FLOATS * sizeof(float), s);
+    hipLaunchKernelGGL(transposed_image_kernel, dim3(16), dim3(256), 0, s, w3t, w3, C2, C3);
+    {   // B1
+        const unsigned grid = bwd_grid(total, 2);
+        const size_t lds = (size_t)L_F32 * 4 + (size_t)(W2_U4 + W3_U4) * 16 + (size_t)WAVES * B1_SCR * 4;
+        hipLaunchKernelGGL(fusion_bn_b1_kernel, dim3(grid), dim3(64 * WAVES), lds, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, grad_out, row_c,
+                           row_dy, row_a, partial);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)grid, 256, 256, sums3);
+    }
+    {   // B2
+        const unsigned grid = bwd_grid(total, 1);
+        hipLaunchKernelGGL(fusion_bn_b2_kernel, dim3(grid), dim3(64 * WAVES), B2_LDS, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, sums3, inv_rows,
+                           w3t, row_c, row_dy, dy2, partial);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((C3 * C2 + 255) / 256), dim3(256), 0, s, partial, (int)grid, B2_G, C3 * C2, grad_weights + G_W3);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial + C3 * C2, (int)grid, B2_G, 2 * C2, sums2);
+    }
+    {   // B3
+        const unsigned grid = bwd_grid(total, 1);
+        hipLaunchKernelGGL(fusion_bn_b3_kernel, dim3(grid), dim3(64 * WAVES), B3_LDS, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, b3, bn, sums2, inv_rows, dy2,
+                           dy1, partial);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((C2 * C1 + 255) / 256), dim3(256), 0, s, partial, (int)grid, B3_G, C2 * C1, grad_weights + G_W2);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial + C2 * C1, (int)grid, B3_G, 2 * C1, sums1);
+    }
+    {   // B4
+        const unsigned grid = bwd_grid(total, 2);
+        hipLaunchKernelGGL(fusion_bn_b4_kernel, dim3(grid), dim3(64 * WAVES), B4_LDS, s, total, n, p1, p2, idx, idx2, w1, b1, b2, b3, bn, sums1, inv_rows, dy1,
+                           row_a, grad_out, grad_p1, grad_nb, partial);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)grid, B4_G, B4_G, grad_weights + G_W1);
+    }
+    // grad_affine: per layer dgamma (= sum dy' zhat) | dbeta (= sum dy')
+    (void)hipMemcpyAsync(grad_affine + 0, sums1 + C1, C1 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(grad_affine + C1, sums1, C1 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(grad_affine + 2 * C1, sums2 + C2, C2 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(grad_affine + 2 * C1 + C2, sums2, C2 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(grad_affine + 2 * C1 + 2 * C2, sums3 + C3, C3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(grad_affine + 2 * C1 + 2 * C2 + C3, sums3, C3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    mcp_prof_end(MCP_KERNEL_FUSION, s);
+    return mcp_launch_status();
 }

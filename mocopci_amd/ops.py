@@ -178,6 +178,50 @@ class _CrossFn(torch.autograd.Function):
         return (None, None, None, d_xyz1, d_xyz2, d_points1, d_points2, *pieces)
 
 
+class _FusionBNFn(torch.autograd.Function):
+    """The fusion layer of one reference call on BATCH statistics (net.train()), forward and backward on the multi-pass kernels of
+    csrc/fusion_bn.hip.  Returns (out, bn, var): bn = per layer mean | rstd | gamma | beta, var = the biased batch variances (both
+    non-differentiable by-products for the caller's running-estimate update)."""
+
+    @staticmethod
+    def forward(ctx, be, eps, ia, ib, p1, p2, w1, b1, w2, b2, w3, b3, g1, e1, g2, e2, g3, e3):
+        conv = [t.detach().contiguous() for t in (w1, b1, w2, b2, w3, b3)]
+        p1, p2 = p1.detach().contiguous(), p2.detach().contiguous()
+        out, bn, var = be.fusion_bn_forward(p1, p2, ia if ib is None else (ia, ib), conv, (g1, e1, g2, e2, g3, e3), eps)
+        ctx.save_for_backward(ia, ib, p1, p2, *conv, bn)
+        ctx.mark_non_differentiable(bn, var)
+        return out, bn, var
+
+    @staticmethod
+    def backward(ctx, grad_out, _gbn, _gvar):
+        ia, ib, p1, p2, w1, b1, w2, b2, w3, b3, bn = ctx.saved_tensors
+        B, N, _ = p1.shape
+        rows = B * N * 64
+        lib, dev = _lib.load(), p1.device
+        grad_out = grad_out.contiguous()
+        row_c = torch.empty((rows,), dtype=torch.int32, device=dev)
+        row_dy, row_a = torch.empty((rows,), dtype=torch.float32, device=dev), torch.empty((rows,), dtype=torch.float32, device=dev)
+        dy2, dy1 = torch.empty((rows, 64), dtype=torch.float32, device=dev), torch.empty((rows, 64), dtype=torch.float32, device=dev)
+        d_p1 = torch.empty_like(p1)
+        d_nb = torch.empty((B, N, 64, 3), dtype=torch.float32, device=dev)
+        d_w = torch.empty((lib.mcp_fusion_grad_floats(),), dtype=torch.float32, device=dev)
+        d_aff = torch.empty((512,), dtype=torch.float32, device=dev)
+        need = lib.mcp_fusion_bn_grad_workspace_bytes(B, N)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _call("mcp_fusion_bn_backward", p1, B, N, 64, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib),
+              *[_lib.fptr(t) for t in (w1, b1, w2, b2, w3, b3, bn, grad_out)], _lib.iptr(row_c), _lib.fptr(row_dy), _lib.fptr(row_a), _lib.fptr(dy2),
+              _lib.fptr(dy1), _lib.fptr(d_p1), _lib.fptr(d_nb), _lib.fptr(d_w), _lib.fptr(d_aff), ws.data_ptr(), need)
+        d_p2 = None
+        if ctx.needs_input_grad[5]:
+            d_p2 = _group_rows_grad(d_nb, ia if ib is None else torch.cat((ia, ib), dim=-1), p2.shape[1])
+        pieces, at = [], 0
+        for t in (w1, b1, w2, b2, w3, b3):
+            pieces.append(d_w[at:at + t.numel()].view(t.shape))
+            at += t.numel()
+        aff = [d_aff[0:64], d_aff[64:128], d_aff[128:192], d_aff[192:256], d_aff[256:384], d_aff[384:512]]
+        return (None, None, None, None, d_p1, d_p2, *pieces, *aff)
+
+
 class _FusionFn(torch.autograd.Function):
     """mcp_fusion with its hand-written backward (mcp_fusion_grad): the layer is re-evaluated inside the backward kernel, the
     neighbour gradients go through the deterministic segmented scatter, weight gradients are fixed-order sums."""
@@ -413,6 +457,12 @@ class HipBackend:
             return self._fusion_mlp(p1, p2, idx, w1, b1, w2, b2, w3, b3)
         ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
         return _FusionFn.apply(self, ia.contiguous(), None if ib is None else ib.contiguous(), p1, p2, w1, b1, w2, b2, w3, b3)
+
+    def fusion_bn(self, p1, p2, idx, conv, affine, eps):
+        """The fusion layer of ONE reference call on batch statistics, differentiable w.r.t. p1, p2, the conv weights and the
+        BatchNorm weight / bias: -> (out (B,N,3), bn, var) -- see _FusionBNFn."""
+        ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
+        return _FusionBNFn.apply(self, float(eps), ia.contiguous(), None if ib is None else ib.contiguous(), p1, p2, *conv, *affine)
 
     def fusion_bn_forward(self, p1, p2, idx, conv, affine, eps):
         """The fusion layer of ONE reference call on batch statistics (net.train(); mocopci.py:810-819 with nn.BatchNorm2d in training

@@ -208,6 +208,70 @@ def test_pointconv_backward_kernel_matches_the_unfused_layer_and_repeats_bit_for
         assert err <= 2e-4 * scale + 2e-5, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
 
 
+def test_fusion_on_batch_statistics_matches_autograd_over_the_unfused_layer_and_repeats_bit_for_bit():
+    """The fusion layer in net.train() mode (csrc/fusion_bn.hip: three statistics passes + the layer; four backward passes with the
+    BatchNorm mean terms) against float64 autograd over the unfused layer with nn.BatchNorm semantics (batch statistics, biased
+    variance, eps 1e-3): output, batch statistics, and the gradients w.r.t. coordinates, conv weights and BatchNorm weight / bias.
+    Points with a neighbour whose arg-max channel or a ReLU is decided by rounding (found in float64) get a zero upstream gradient."""
+    be = ops.backend()
+    B, N = 2, 701
+    p1 = cloud(160, B, N).to(DEV)
+    p2 = p1 + rnd(161, B, N, 3, scale=0.2).to(DEV)
+    halves = (be.knn(p1, p1, 32), be.knn(p1, p2, 32))
+    conv = [t.to(DEV) for t in (rnd(162, 64, 4, scale=0.5), rnd(163, 64, scale=0.3), rnd(164, 64, 64, scale=0.125), rnd(165, 64, scale=0.3),
+                                rnd(166, 128, 64, scale=0.125), rnd(167, 128, scale=0.3))]
+    aff = [t.to(DEV) for t in (1 + rnd(168, 64, scale=0.2), rnd(169, 64, scale=0.2), 1 + rnd(170, 64, scale=0.2), rnd(171, 64, scale=0.2),
+                               1 + rnd(172, 128, scale=0.2), rnd(173, 128, scale=0.2))]
+    whole = torch.cat(halves, dim=-1).long()
+    bi = torch.arange(B, device=DEV).view(B, 1, 1)
+
+    def unfused(a, b, *wa):  # float64, mocopci.py:803-819 with BatchNorm2d in training mode
+        w, af = wa[:6], wa[6:]
+        nb = b[bi, whole]
+        r = nb - a.unsqueeze(2)
+        x = torch.cat([r, r.norm(dim=-1, keepdim=True)], dim=-1)
+        pre = []
+        for i in range(3):
+            z = x @ w[2 * i].T + w[2 * i + 1]
+            flat = z.reshape(-1, z.shape[-1])
+            mean, var = flat.mean(0), flat.var(0, unbiased=False)
+            v = (z - mean) * (af[2 * i] * torch.rsqrt(var + 1e-3)) + af[2 * i + 1]
+            pre.append((v, mean, var))
+            x = torch.relu(v)
+        wgt = torch.softmax(x.max(dim=-1)[0], dim=-1)
+        return torch.sum(wgt.unsqueeze(-1) * nb, dim=2), pre
+    leaves64 = [t.detach().double().clone().requires_grad_(True) for t in (p1, p2, *conv, *aff)]
+    want_out, pre = unfused(*leaves64)
+    top2 = torch.relu(pre[2][0]).topk(2, dim=-1).values
+    clear = ((top2[..., 0] - top2[..., 1]) > 1e-4 * (1.0 + top2[..., 0])).all(dim=-1)
+    clear &= (pre[0][0].abs().amin(dim=(2, 3)) > 1e-5) & (pre[1][0].abs().amin(dim=(2, 3)) > 1e-5)
+    assert float(clear.float().mean()) > 0.8
+    g = rnd(174, B, N, 3).to(DEV) * clear.unsqueeze(-1).float()
+    want = torch.autograd.grad(want_out, leaves64, g.double())
+
+    def run():
+        leaves = [t.detach().clone().requires_grad_(True) for t in (p1, p2, *conv, *aff)]
+        out, bn, var = be.fusion_bn(leaves[0], leaves[1], halves, leaves[2:8], leaves[8:], 1e-3)
+        return out, bn, var, torch.autograd.grad(out, leaves, g)
+    out, bn, var, got = run()
+    out2, bn2, var2, got2 = run()
+    assert torch.equal(out, out2) and torch.equal(bn, bn2) and torch.equal(var, var2)
+    torch.testing.assert_close(out.double(), want_out.detach(), rtol=1e-4, atol=1e-4)
+    off = 0
+    for i, c in enumerate((64, 64, 128)):
+        torch.testing.assert_close(bn[4 * off:4 * off + c].double(), pre[i][1].detach(), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(var[off:off + c].double(), pre[i][2].detach(), rtol=1e-4, atol=1e-6)
+        off += c
+    names = ["p1", "p2", "w1", "b1", "w2", "b2", "w3", "b3", "gamma1", "beta1", "gamma2", "beta2", "gamma3", "beta3"]
+    for name, a, a2, b in zip(names, got, got2, want):
+        assert torch.equal(a, a2), name
+        assert torch.isfinite(a).all(), name
+        scale = float(b.abs().max())
+        err = float((a.double() - b).abs().max())
+        floor = 2e-5 if not name.startswith("b") or name.startswith("beta") else 1e-3   # conv biases: exactly 0 here, rounding noise in autograd
+        assert err <= 5e-4 * scale + floor, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
+
+
 def test_ptblock_gradients():
     n = 333
     xyz = cloud(40, 2, n)
