@@ -938,6 +938,31 @@ class MoCoPCI(nn.Module):
         call at a time; the running statistics are updated here, outside the recomputed function, from the statistics it returns."""
         m = "multi_frame_inference.conv."
         layers = ((0, 1), (3, 4), (6, 7))
+        be = ops.backend()
+        if hasattr(be, "fusion_bn"):
+            # the multi-pass kernels of csrc/fusion_bn.hip: statistics passes + the layer, and a backward with the BatchNorm mean
+            # terms; nothing of size rows x channels is kept (the unfused form below is what the oracle backend runs)
+            P = self._params()
+            conv = [t for ci, _ in layers for t in (self.W(m + str(ci)), self.Bv(m + str(ci)))]
+            aff = [t for _, bi in layers for t in (P[m + f"{bi}.weight"], P[m + f"{bi}.bias"])]
+            per = p1.shape[0] // calls
+            rows = per * p1.shape[1] * 64
+            outs = []
+            for c in range(calls):
+                sl = slice(c * per, (c + 1) * per)
+                idx_c = tuple(i[sl] for i in idx) if isinstance(idx, (tuple, list)) else idx[sl]
+                out, bn, var = be.fusion_bn(p1[sl], p2[sl], idx_c, conv, aff, 1e-3)
+                outs.append(out)
+                with torch.no_grad():
+                    at_bn = at_var = 0
+                    for (_, bi), ch in zip(layers, (64, 64, 128)):
+                        rm, rv, mom = P[m + f"{bi}.running_mean"], P[m + f"{bi}.running_var"], self.BN_MOMENTUM
+                        rm.mul_(1.0 - mom).add_(bn[at_bn:at_bn + ch], alpha=mom)
+                        rv.mul_(1.0 - mom).add_(var[at_var:at_var + ch], alpha=mom * rows / (rows - 1))
+                        P[m + f"{bi}.num_batches_tracked"].add_(1)
+                        at_bn += 4 * ch
+                        at_var += ch
+            return torch.cat(outs, dim=0)
         idx = grad.whole(idx)
         if p1.shape[0] * p1.shape[1] * idx.shape[-1] * 128 * 4 <= self.CHECKPOINT_BYTES or not torch.is_grad_enabled():
             nb = ops.backend().group_rows(p2, idx)                                    # (B,N,64,3)
