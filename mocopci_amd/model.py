@@ -263,6 +263,7 @@ class MoCoPCI(nn.Module):
         keep = torch.empty(x.shape[:2] + (1,) * (x.dim() - 2), device=x.device, dtype=x.dtype).bernoulli_(1.0 - p)
         return x * (keep / (1.0 - p))
 
+    SDPA_DROPOUT = True         # net.train() on the GPU: attention dropout inside the library's fused attention kernel
     CHECKPOINT_BYTES = 1 << 30  # net.train() forwards: unfused blocks whose intermediates exceed this are recomputed in the backward, in chunks of about this size
 
     def attend(self, q, kv, heads, scale=None):
@@ -276,6 +277,14 @@ class MoCoPCI(nn.Module):
         BF, Nq, C = q.shape
         Nk, hd = kv.shape[1], C // heads
         sc = hd ** -0.5 if scale is None else scale
+        if q.is_cuda and self.SDPA_DROPOUT:
+            # the library's fused attention draws the dropout mask inside the kernel (forward and backward from one counter-based
+            # stream seeded by torch's generator): same distribution as softmax -> F.dropout -> matmul, nothing of size
+            # heads x Nq x Nk exists.  The CPU (oracle backend) path below keeps the explicit form.
+            qh = q.reshape(BF, Nq, heads, hd).permute(0, 2, 1, 3)
+            kvh = kv.reshape(BF, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+            o = F.scaled_dot_product_attention(qh, kvh[0], kvh[1], dropout_p=p, scale=sc)
+            return o.permute(0, 2, 1, 3).reshape(BF, Nq, C)
 
         def dense(q_, kv_):
             n = q_.shape[0]
