@@ -425,6 +425,22 @@ int mcp_ptblock_pack(const float *wd1, const float *bd1, const float *wd2, const
 int mcp_ptblock_attention(int b, int n, int c, int k, int qkv_stride, const float *xyz, const float *q, const float *kf,
                           const float *vf, const int *idx, const float *packed, float *out, mcp_stream_t stream);
 
+/* Backward of mcp_ptblock_attention for a block given by its own weights wd1 (64,3), bd1, wd2 (64,64), bd2 (fc_delta), wg1, bg1, wg2,
+ * bg2 (fc_gamma) (the reference differentiates pointT_layer2.py:64-75 with autograd over five (B,N,16,64) tensors).  xyz, q, kf,
+ * vf, idx, qkv_stride as mcp_ptblock_attention; grad_out (B,N,64).  Writes
+ *   grad_q (B,N,64); grad_xyz_c (B,N,3): the centre's share of dL/dxyz;
+ *   grad_xyz_rows (B,N,16,3), grad_k_rows, grad_v_rows (B,N,16,64): per gathered neighbour, for the caller's deterministic scatter
+ *       (mcp_group_rows_grad_sorted) into dL/dxyz, dL/dk, dL/dv;
+ *   grad_weights: mcp_ptblock_grad_floats() floats = dWd1 (64,3) | dbd1 | dWd2 (64,64) | dbd2 | dWg1 | dbg1 | dWg2 | dbg2.
+ * The block is re-evaluated in the kernel; all sums run in fixed orders.  workspace: mcp_ptblock_grad_workspace_bytes(b, n),
+ * 16-byte aligned.  c = 64, k = 16. */
+int mcp_ptblock_grad_floats(void);
+size_t mcp_ptblock_grad_workspace_bytes(int b, int n);
+int mcp_ptblock_grad(int b, int n, int c, int k, int qkv_stride, const float *xyz, const float *q, const float *kf, const float *vf, const int *idx,
+                     const float *wd1, const float *bd1, const float *wd2, const float *bd2, const float *wg1, const float *bg1, const float *wg2,
+                     const float *bg2, const float *grad_out, float *grad_xyz_c, float *grad_xyz_rows, float *grad_q, float *grad_k_rows,
+                     float *grad_v_rows, float *grad_weights, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+
 /* Approximate Earth Mover's Distance (metric of test.py:90): approxmatch + matchcost of
  * models/EMD/cuda/emd_kernel.cu:29-162, :204-247 (emd_cuda.approxmatch_forward / matchcost_forward, emd.py:11-12).
  * xyz1 (B,N,3), xyz2 (B,M,3) -> cost (B) = sum_{l,k} match[l][k] |xyz2[l]-xyz1[k]|^2.  match (B,M,N) is written

@@ -74,6 +74,9 @@ SIGNATURES = {
     "mcp_ptblock_packed_floats": [],
     "mcp_ptblock_pack": [_p] * 10,
     "mcp_ptblock_attention": [_i] * 5 + [_p] * 8,
+    "mcp_ptblock_grad_floats": [],
+    "mcp_ptblock_grad_workspace_bytes": [_i, _i],
+    "mcp_ptblock_grad": [_i] * 5 + [_p] * 21 + [ctypes.c_size_t, _p],
     "mcp_linear_packed_floats": [_i, _i, _p],
     "mcp_linear_pack": [_i, _i, _p, _p, _p, _p, _p],
     "mcp_attention": [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _f, _p, _i, _p],
@@ -91,7 +94,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": ctypes.c_size_t, "mcp_fusion_grad_workspace_bytes": ctypes.c_size_t,
              "mcp_cross_grad_workspace_bytes": ctypes.c_size_t, "mcp_pointconv_agg_grad_workspace_bytes": ctypes.c_size_t,
-             "mcp_fusion_bn_workspace_bytes": ctypes.c_size_t, "mcp_fusion_bn_grad_workspace_bytes": ctypes.c_size_t}
+             "mcp_fusion_bn_workspace_bytes": ctypes.c_size_t, "mcp_fusion_bn_grad_workspace_bytes": ctypes.c_size_t,
+             "mcp_ptblock_grad_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

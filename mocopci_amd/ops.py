@@ -178,6 +178,48 @@ class _CrossFn(torch.autograd.Function):
         return (None, None, None, d_xyz1, d_xyz2, d_points1, d_points2, *pieces)
 
 
+class _PtblockFn(torch.autograd.Function):
+    """mcp_ptblock_attention with its hand-written backward (mcp_ptblock_grad): the block re-evaluated in the backward kernel, the
+    per-neighbour gradients through the deterministic segmented scatter (one sort serves xyz, k and v), weight gradients fixed-order."""
+
+    @staticmethod
+    def forward(ctx, be, idx, xyz, q, k, v, *weights):
+        xyz = xyz.detach().contiguous()
+        q, k, v = q.detach(), k.detach(), v.detach()
+        if not (q.stride() == k.stride() == v.stride() and q.stride(2) == 1 and q.stride(0) == q.shape[1] * q.stride(1)):
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        ws = [t.detach().contiguous() for t in weights]
+        ctx.save_for_backward(idx, xyz, q, k, v, *ws)
+        return be.ptblock_attention(xyz, q, k, v, idx, be.ptblock_pack(*ws))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, xyz, q, k, v, *ws = ctx.saved_tensors
+        B, N, C = q.shape
+        lib, dev = _lib.load(), q.device
+        grad_out = grad_out.contiguous()
+        d_xyz_c = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        d_xyz_rows = torch.empty((B, N, 16, 3), dtype=torch.float32, device=dev)
+        d_q = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        d_k_rows = torch.empty((B, N, 16, C), dtype=torch.float32, device=dev)
+        d_v_rows = torch.empty((B, N, 16, C), dtype=torch.float32, device=dev)
+        d_w = torch.empty((lib.mcp_ptblock_grad_floats(),), dtype=torch.float32, device=dev)
+        need = lib.mcp_ptblock_grad_workspace_bytes(B, N)
+        wsp = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _call("mcp_ptblock_grad", q, B, N, C, 16, q.stride(1), _lib.fptr(xyz), q.data_ptr(), k.data_ptr(), v.data_ptr(), _lib.iptr(idx),
+              *[_lib.fptr(t) for t in ws], _lib.fptr(grad_out), _lib.fptr(d_xyz_c), _lib.fptr(d_xyz_rows), _lib.fptr(d_q), _lib.fptr(d_k_rows),
+              _lib.fptr(d_v_rows), _lib.fptr(d_w), wsp.data_ptr(), need)
+        segments = _scatter_segments(idx, N)
+        d_xyz = d_xyz_c + _group_rows_grad(d_xyz_rows, idx, N, segments) if ctx.needs_input_grad[2] else None
+        d_k = _group_rows_grad(d_k_rows, idx, N, segments) if ctx.needs_input_grad[4] else None
+        d_v = _group_rows_grad(d_v_rows, idx, N, segments) if ctx.needs_input_grad[5] else None
+        pieces, at = [], 0
+        for t in ws:
+            pieces.append(d_w[at:at + t.numel()].view(t.shape))
+            at += t.numel()
+        return (None, None, d_xyz, d_q, d_k, d_v, *pieces)
+
+
 class _FusionBNFn(torch.autograd.Function):
     """The fusion layer of one reference call on BATCH statistics (net.train()), forward and backward on the multi-pass kernels of
     csrc/fusion_bn.hip.  Returns (out, bn, var): bn = per layer mean | rstd | gamma | beta, var = the biased batch variances (both
@@ -545,6 +587,8 @@ class HipBackend:
         def fused(x, q_, k_, v_, i, *w):
             pk = packed if packed is not None else self.ptblock_pack(*w)
             return self.ptblock_attention(x.contiguous(), q_, k_, v_, i, pk)
+        if grad.wants_grad(xyz, q, k, v, *weights) and q.shape[-1] == 64 and idx.shape[-1] == 16:
+            return _PtblockFn.apply(self, idx.contiguous(), xyz, q, k, v, *weights)
         return grad.run(fused, lambda *a: grad.ptblock_twin(self.group_rows, *a), xyz, q, k, v, idx, *weights)
 
     def ptblock_pack(self, wd1, bd1, wd2, bd2, wg1, bg1, wg2, bg2):

@@ -272,6 +272,45 @@ def test_fusion_on_batch_statistics_matches_autograd_over_the_unfused_layer_and_
         assert err <= 5e-4 * scale + floor, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
 
 
+def test_ptblock_backward_kernel_matches_the_unfused_block_and_repeats_bit_for_bit():
+    """mcp_ptblock_grad against autograd over the unfused block (grad.ptblock_twin) on the device: q, k, v as slices of one packed
+    projection (row stride 192), an odd point count (the last wave holds one point); two runs give identical bits.  Points with a
+    ReLU input on the kink (found in float64) get a zero upstream gradient."""
+    from mocopci_amd import grad
+    be = ops.backend()
+    B, n = 3, 1001
+    xyz = cloud(180, B, n).to(DEV)
+    qkv = rnd(181, B, n, 192).to(DEV)
+    idx = be.knn(xyz, xyz, 16)
+    ws = [rnd(182, 64, 3, scale=0.3), rnd(183, 64, scale=0.1)]
+    for i in range(3):
+        ws += [rnd(184 + i, 64, 64, scale=0.125), rnd(188 + i, 64, scale=0.1)]
+    ws = [t.to(DEV) for t in ws]
+    bi = torch.arange(B, device=DEV).view(B, 1, 1)
+    x64, q64 = xyz.double(), qkv.double()
+    d1 = (x64.unsqueeze(2) - x64[bi, idx.long()]) @ ws[0].double().T + ws[1].double()
+    gpre = (q64[..., :64].unsqueeze(2) - q64[..., 64:128][bi, idx.long()]) + torch.relu(d1) @ ws[2].double().T + ws[3].double()
+    a1 = gpre @ ws[4].double().T + ws[5].double()
+    clear = (d1.abs().amin(dim=(2, 3)) > 1e-5) & (a1.abs().amin(dim=(2, 3)) > 1e-5)
+    assert float(clear.float().mean()) > 0.8
+    g = rnd(192, B, n, 64).to(DEV) * clear.unsqueeze(-1).float()
+    names = ["xyz", "qkv", "wd1", "bd1", "wd2", "bd2", "wg1", "bg1", "wg2", "bg2"]
+
+    def grads(fn):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (xyz, qkv, *ws)]
+        x, p = leaves[0], leaves[1]
+        return torch.autograd.grad(fn(x, p[..., :64], p[..., 64:128], p[..., 128:], leaves[2:]), leaves, g)
+    hip = grads(lambda x, a, b, c, w: be.ptblock_layer(x, a, b, c, idx, w))
+    again = grads(lambda x, a, b, c, w: be.ptblock_layer(x, a, b, c, idx, w))
+    want = grads(lambda x, a, b, c, w: grad.ptblock_twin(be.group_rows, x, a, b, c, idx, *w))
+    for name, a, a2, b in zip(names, hip, again, want):
+        assert torch.equal(a, a2), name
+        assert torch.isfinite(a).all(), name
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        assert err <= 2e-4 * scale + 2e-5, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
+
+
 def test_ptblock_gradients():
     n = 333
     xyz = cloud(40, 2, n)
