@@ -1393,9 +1393,14 @@ class MoCoPCI(nn.Module):
         gt_frame = []
         if gt is not None:
             with torch.no_grad():
-                for g in gt:                                                       # downsampling(), mocopci.py:1099-1104
-                    gcl = g.transpose(1, 2).contiguous()
-                    gt_frame.append([g] + [self.fps_gather(gcl, N // d).transpose(1, 2).contiguous() for d in (4, 16, 32)])
+                # downsampling(), mocopci.py:1099-1104: every ground-truth frame sampled to N/4, N/16 and N/32 points, each from the
+                # full cloud.  Furthest point sampling is sequential from index 0, so the N/16 and N/32 samples are the first points
+                # of the N/4 sample (bit for bit), and the frames are independent clouds: one launch instead of nine.
+                Bg = gt[0].shape[0]
+                pts = self.fps_gather(torch.cat([g.transpose(1, 2) for g in gt], dim=0).contiguous(), N // 4)
+                for i, g in enumerate(gt):
+                    p = pts[i * Bg:(i + 1) * Bg]
+                    gt_frame.append([g] + [p[:, :N // d].transpose(1, 2).contiguous() for d in (4, 16, 32)])
         frames_lst_f = [[lst[i] for lst in flows_f] for i in range(3)]
         frames_lst_b = [[lst[i] for lst in flows_b] for i in range(3)]
         return frames_lst_f, frames_lst_b, gt_frame, out_lst

@@ -178,6 +178,34 @@ class _CrossFn(torch.autograd.Function):
         return (None, None, None, d_xyz1, d_xyz2, d_points1, d_points2, *pieces)
 
 
+class _LinearFn(torch.autograd.Function):
+    """The fused Linear (+ one-slope activation, + residual) with an explicit backward: two GEMMs and a mask taken from the saved
+    OUTPUT (for 0 <= slope <= 1 the output of act is positive exactly where its argument is), instead of evaluating the layer again under autograd."""
+
+    @staticmethod
+    def forward(ctx, fused, x, w, b, slope, res):
+        y = fused(x.detach(), w.detach(), None if b is None else b.detach(), slope, None if res is None else res.detach())
+        ctx.slope, ctx.has_b, ctx.has_res = float(slope), b is not None, res is not None
+        ctx.save_for_backward(x, w, y if slope != 1.0 else None, res if (res is not None and slope != 1.0) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w, y, res = ctx.saved_tensors
+        n, k = w.shape
+        gy = grad_out.reshape(-1, n)
+        if ctx.slope != 1.0:
+            act = (y if res is None else y - res).reshape(-1, n)
+            gz = torch.where(act > 0, gy, gy * ctx.slope)
+        else:
+            gz = gy
+        dx = (gz @ w).reshape(x.shape) if ctx.needs_input_grad[1] else None
+        dw = gz.t() @ x.reshape(-1, k) if ctx.needs_input_grad[2] else None
+        db = gz.sum(dim=0) if ctx.has_b and ctx.needs_input_grad[3] else None
+        dres = grad_out if ctx.has_res and ctx.needs_input_grad[5] else None
+        return None, dx, dw, db, None, dres
+
+
 class _PtblockFn(torch.autograd.Function):
     """mcp_ptblock_attention with its hand-written backward (mcp_ptblock_grad): the block re-evaluated in the backward kernel, the
     per-neighbour gradients through the deterministic segmented scatter (one sort serves xyz, k and v), weight gradients fixed-order."""
@@ -801,6 +829,8 @@ class HipBackend:
             return out.reshape(*first.shape[:-1], n)
         if isinstance(xs, (tuple, list)) and grad.wants_grad(*xs, w, b, res):
             return grad.linear_twin(xs, w, b, slope, res)  # training: plain autograd over the concatenation
+        if grad.wants_grad(xs, w, b, res) and isinstance(slope, (int, float)) and 0.0 <= slope <= 1.0:
+            return _LinearFn.apply(fused, xs, w, b, float(slope), res)
         return grad.run(fused, grad.linear_twin, xs, w, b, slope, res)
 
     def linear_narrow_supported(self, rows, k, n):

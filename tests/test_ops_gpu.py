@@ -830,3 +830,17 @@ def test_linear_few_rows_split_k_matches_unfused_oracle(rows, ks, n, slope, with
     got = call()
     torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
     assert torch.equal(call(), got)
+
+
+def test_furthest_point_samples_are_prefixes_of_longer_samples():
+    """What MoCoPCI.forward(train=True) relies on for the ground-truth pyramid (mocopci.py:1099-1104): the N/16 and N/32 samples of
+    a cloud are the first points of its N/4 sample, and a cloud's sample does not depend on the batch it is sampled in."""
+    import torch
+    from mocopci_amd import ops
+    be = ops.backend()
+    g = torch.Generator().manual_seed(77)
+    clouds = ((torch.rand(5, 8192, 3, generator=g) * 2 - 1) * 20).cuda()
+    long = be.fps(clouds, 2048)
+    for m in (512, 256):
+        assert torch.equal(be.fps(clouds, m), long[:, :m])
+    assert torch.equal(be.fps(clouds[1:3].contiguous(), 2048), long[1:3])
