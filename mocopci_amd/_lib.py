@@ -70,6 +70,8 @@ SIGNATURES = {
     "mcp_pointconv_linear": [_i] * 5 + [_p] * 11 + [_i, _f, _p, _p],
     "mcp_attention_small": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
     "mcp_attention_wide": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _i, _p],
+    "mcp_attention_small_grad_workspace_bytes": [_i, _i, _i],
+    "mcp_attention_small_grad": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _p, ctypes.c_size_t, _p],
     "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_ptblock_packed_floats": [],
     "mcp_ptblock_pack": [_p] * 10,
@@ -95,7 +97,7 @@ SIGNATURES = {
 _RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": ctypes.c_size_t, "mcp_fusion_grad_workspace_bytes": ctypes.c_size_t,
              "mcp_cross_grad_workspace_bytes": ctypes.c_size_t, "mcp_pointconv_agg_grad_workspace_bytes": ctypes.c_size_t,
              "mcp_fusion_bn_workspace_bytes": ctypes.c_size_t, "mcp_fusion_bn_grad_workspace_bytes": ctypes.c_size_t,
-             "mcp_ptblock_grad_workspace_bytes": ctypes.c_size_t}
+             "mcp_ptblock_grad_workspace_bytes": ctypes.c_size_t, "mcp_attention_small_grad_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

@@ -178,6 +178,32 @@ class _CrossFn(torch.autograd.Function):
         return (None, None, None, d_xyz1, d_xyz2, d_points1, d_points2, *pieces)
 
 
+class _AttentionSmallFn(torch.autograd.Function):
+    """mcp_attention_small (head dims 8 / 16) with its hand-written backward (mcp_attention_small_grad: row statistics, dQ, dK/dV)."""
+
+    @staticmethod
+    def forward(ctx, be, q, kv, heads, scale):
+        q, kv = q.detach().contiguous(), kv.detach().contiguous()
+        out = be._attention(q, kv, heads, scale)
+        ctx.heads, ctx.scale = heads, scale
+        ctx.save_for_backward(q, kv, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, kv, out = ctx.saved_tensors
+        BF, Nq, C = q.shape
+        Nk, heads = kv.shape[1], ctx.heads
+        lib = _lib.load()
+        grad_out = grad_out.contiguous()
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        need = lib.mcp_attention_small_grad_workspace_bytes(BF, Nq, heads)
+        ws = torch.empty((need,), dtype=torch.uint8, device=q.device)
+        _call("mcp_attention_small_grad", q, BF, Nq, Nk, heads, C // heads, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
+              float(ctx.scale), _lib.fptr(out), _lib.fptr(grad_out), _lib.fptr(dq), _lib.fptr(dkv), ws.data_ptr(), need)
+        return None, dq, dkv, None, None
+
+
 class _LinearFn(torch.autograd.Function):
     """The fused Linear (+ one-slope activation, + residual) with an explicit backward: two GEMMs and a mask taken from the saved
     OUTPUT (for 0 <= slope <= 1 the output of act is positive exactly where its argument is), instead of evaluating the layer again under autograd."""
@@ -694,6 +720,8 @@ class HipBackend:
             scale = hd ** -0.5
         if hd not in (8, 16, 32, 64, 256):  # head dims neither kernel is built for: the dense formulation (same arithmetic as the twin)
             return grad.attention_twin(q, kv, heads, float(scale))
+        if hd in (8, 16) and grad.wants_grad(q, kv):
+            return _AttentionSmallFn.apply(self, q, kv, heads, float(scale))
         return grad.run(self._attention, grad.attention_twin, q, kv, heads, float(scale))
 
     def _attention(self, q, kv, heads, scale):

@@ -272,6 +272,33 @@ def test_fusion_on_batch_statistics_matches_autograd_over_the_unfused_layer_and_
         assert err <= 5e-4 * scale + floor, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
 
 
+@pytest.mark.parametrize("heads,hd,nq,nk,bf", [(8, 8, 333, 517, 3), (8, 8, 2048, 2048, 2), (4, 16, 200, 64, 2), (8, 16, 130, 1000, 1)])
+def test_attention_small_backward_kernels_match_the_dense_formulation_and_repeat(heads, hd, nq, nk, bf):
+    """mcp_attention_small_grad against float64 autograd over softmax(q k^T scale) v: ragged query / key counts (partial tiles on both
+    sides), both head widths; two runs give identical bits."""
+    be = ops.backend()
+    C = heads * hd
+    q, kv, g = rnd(200, bf, nq, C).to(DEV), rnd(201, bf, nk, 2 * C).to(DEV), rnd(202, bf, nq, C).to(DEV)
+
+    def grads(fn, dt):
+        leaves = [t.detach().to(dt).clone().requires_grad_(True) for t in (q, kv)]
+        return torch.autograd.grad(fn(*leaves), leaves, g.to(dt))
+
+    def dense(a, b):
+        qh = a.reshape(bf, nq, heads, hd).permute(0, 2, 1, 3)
+        kvh = b.reshape(bf, nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
+        p = torch.softmax(qh @ kvh[0].transpose(-2, -1) * hd ** -0.5, dim=-1)
+        return (p @ kvh[1]).permute(0, 2, 1, 3).reshape(bf, nq, C)
+    hip = grads(lambda a, b: be.attention(a, b, heads), torch.float32)
+    again = grads(lambda a, b: be.attention(a, b, heads), torch.float32)
+    want = grads(dense, torch.float64)
+    for name, a, a2, b in zip(("q", "kv"), hip, again, want):
+        assert torch.equal(a, a2), name
+        scale = float(b.abs().max())
+        err = float((a.double() - b).abs().max())
+        assert err <= 1e-4 * scale + 1e-6, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
+
+
 def test_ptblock_backward_kernel_matches_the_unfused_block_and_repeats_bit_for_bit():
     """mcp_ptblock_grad against autograd over the unfused block (grad.ptblock_twin) on the device: q, k, v as slices of one packed
     projection (row stride 192), an odd point count (the last wave holds one point); two runs give identical bits.  Points with a
