@@ -355,15 +355,24 @@ int mcp_attention_wide(int bf, int nq, int nk, int heads, int hd, const float *q
 int mcp_attention(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
                   const float *v, int v_stride, int kv_batch_shift, float scale, float *out, int out_stride, mcp_stream_t stream);
 
-/* Backward of mcp_attention_small (head_dim 8 / 16; the reference differentiates the materialised softmax of mocopci.py:72-86,
- * :650-667 with autograd).  q, k, v, strides, scale as the forward (no key / value batch shift); out (BF,Nq,heads*hd) the forward's
- * output, grad_out its gradient, both dense.  Writes grad_q (BF,Nq,heads*hd) and grad_kv (BF,Nk,2*heads*hd) laid out [dK | dV]
- * like the reference's kv projection.  Three kernels (row statistics, dQ, dK/dV); nothing of size Nq x Nk is written; fixed
- * summation orders.  workspace: mcp_attention_small_grad_workspace_bytes(bf, nq, heads) bytes. */
+/* mcp_attention_small with attention dropout (net.train(): mocopci.py:660-662 / :80-82 drop entries of the softmax matrix): out =
+ * dropout(softmax(q k^T scale), drop_p) v per head; the softmax is normalised before the mask, kept entries are scaled by
+ * 1 / (1 - drop_p).  The mask is a counter-based hash of (seed, batch, head, query, key): the caller draws `seed` from its generator
+ * per call; the backward regenerates the mask from the same seed.  Not the reference generator's mask for a given torch seed (no
+ * kernel can be: the reference materialises the matrix and draws it with torch's Philox stream), the same distribution. */
+int mcp_attention_small_dropout(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
+                                int v_stride, float scale, float drop_p, unsigned seed, float *out, mcp_stream_t stream);
+
+/* Backward of mcp_attention_small / mcp_attention_small_dropout (head_dim 8 / 16; the reference differentiates the materialised
+ * softmax of mocopci.py:72-86, :650-667 with autograd).  q, k, v, strides, scale as the forward (no key / value batch shift);
+ * drop_p, seed as the forward's (0: no dropout); out (BF,Nq,heads*hd) the forward's output, grad_out its gradient, both dense.
+ * Writes grad_q (BF,Nq,heads*hd) and grad_kv (BF,Nk,2*heads*hd) laid out [dK | dV] like the reference's kv projection.  Three
+ * kernels (row statistics, dQ, dK/dV); nothing of size Nq x Nk is written; fixed summation orders.
+ * workspace: mcp_attention_small_grad_workspace_bytes(bf, nq, heads) bytes. */
 size_t mcp_attention_small_grad_workspace_bytes(int bf, int nq, int heads);
 int mcp_attention_small_grad(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
-                             int v_stride, float scale, const float *out, const float *grad_out, float *grad_q, float *grad_kv, void *workspace,
-                             size_t workspace_bytes, mcp_stream_t stream);
+                             int v_stride, float scale, float drop_p, unsigned seed, const float *out, const float *grad_out, float *grad_q,
+                             float *grad_kv, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
 
 /* Row normalisation with the additions in front of it (nn.LayerNorm semantics: biased variance, eps inside the root):
  *     z = x[r] (+ y[r]) (+ bias);   out[r] = (z - mean z) * rsqrt(var z + eps) (* gamma + beta)

@@ -36,6 +36,133 @@ struct Stage {
     static constexpr int PAD = KT * KS, PLAIN = KT * HD;
 };
 
+// Attention dropout (net.train(): mocopci.py:660-662 drops entries of the softmax matrix at rate 0.05).  The keep / drop decision of
+// entry (row, key) is a counter-based hash of (seed, row, key) -- row = the query's index over (batch, head, query) -- so the forward
+// and both backward kernels regenerate the same mask without storing it.  m = 1 / (1 - p) for a kept entry, 0 for a dropped one.
+__device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t row, uint32_t key, uint32_t threshold, float inv_keep) {
+    uint32_t x = seed ^ (row * 0x9E3779B1u) ^ (key * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x >= threshold ? inv_keep : 0.f;
+}
+
+// ---- the forward with dropout: mcp_attention_small's kernel (attention.hip) with the mask applied to P in P.V only (the row sums
+// that normalise the softmax are taken before the mask, as softmax -> dropout -> matmul does) ----
+template <int HD>
+__global__ __launch_bounds__(64 * WAVES) void attention_small_drop_kernel(int nq, int nk, int heads, const float *__restrict__ q, int qs,
+                                                                          const float *__restrict__ k, int ks, const float *__restrict__ v, int vs,
+                                                                          float scale_log2e, uint32_t seed, uint32_t threshold, float inv_keep,
+                                                                          float *__restrict__ out) {
+    constexpr int KS = HD + 1;
+    __shared__ float kt[2][KT * KS];
+    __shared__ __attribute__((aligned(16))) float vt[2][KT * HD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    const int head = blockIdx.y, bf = blockIdx.z;
+    const int qi = blockIdx.x * (32 * WAVES) + wave * 32 + col;
+    const bool live = qi < nq;
+    const size_t qrow = (size_t)bf * nq + (live ? qi : 0);
+    const uint32_t row = (uint32_t)(((size_t)bf * heads + head) * nq + qi);
+    q += qrow * qs + head * HD;
+    k += (size_t)bf * nk * ks + head * HD;
+    v += (size_t)bf * nk * vs + head * HD;
+    float qf[HD / 2];
+#pragma unroll
+    for (int s = 0; s < HD / 2; ++s) qf[s] = q[2 * s + h] * scale_log2e;
+    float m = -INFINITY, l = 0.f, o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    constexpr int F4 = KT * HD / 4, LOADS = (2 * F4 + 64 * WAVES - 1) / (64 * WAVES);
+    float4 pre[LOADS];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < LOADS; ++u) {
+            const int e = tid + u * 64 * WAVES;
+            const bool isv = e >= F4;
+            const int f = isv ? e - F4 : e, r_ = f / (HD / 4), c4 = f % (HD / 4), key = t * KT + r_;
+            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 2 * F4 && key < nk) pre[u] = *reinterpret_cast<const float4 *>((isv ? v + (size_t)key * vs : k + (size_t)key * ks) + c4 * 4);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < LOADS; ++u) {
+            const int e = tid + u * 64 * WAVES;
+            if (e >= 2 * F4) continue;
+            const bool isv = e >= F4;
+            const int f = isv ? e - F4 : e, r_ = f / (HD / 4), c4 = f % (HD / 4);
+            if (isv) {
+                *reinterpret_cast<float4 *>(&vt[buf][r_ * HD + c4 * 4]) = pre[u];
+            } else {
+                float *dst = &kt[buf][r_ * KS + c4 * 4];
+                dst[0] = pre[u].x; dst[1] = pre[u].y; dst[2] = pre[u].z; dst[3] = pre[u].w;
+            }
+        }
+    };
+    const int stages = (nk + KT - 1) / KT;
+    fetch(0);
+    stash(0);
+    for (int t = 0; t < stages; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < stages) fetch(t + 1);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            const float *ka = &kt[cur][(sub * 32 + col) * KS + h];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qf[s], acc, 0, 0, 0);
+            const int kbase = t * KT + sub * 32;
+            if (kbase + 32 > nk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + chan_of(r, h) >= nk) acc[r] = -INFINITY;
+            }
+            float mt = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, acc[r]);
+            const float mn = fmaxf(m, mt);
+            if (mn == -INFINITY) continue;
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[d] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(acc[r] - mn);
+                l += p;
+                float pm = p * drop_scale(seed, row, (uint32_t)(kbase + chan_of(r, h)), threshold, inv_keep);
+                int off = (sub * 32 + chan_of(r, h)) * HD;
+                asm volatile("" : "+v"(off), "+v"(pm));
+                const float *vr = &vt[cur][off];
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 vv = *reinterpret_cast<const float4 *>(vr + d);
+                    o[d + 0] = __builtin_fmaf(pm, vv.x, o[d + 0]);
+                    o[d + 1] = __builtin_fmaf(pm, vv.y, o[d + 1]);
+                    o[d + 2] = __builtin_fmaf(pm, vv.z, o[d + 2]);
+                    o[d + 3] = __builtin_fmaf(pm, vv.w, o[d + 3]);
+                }
+                pin(o);
+            }
+        }
+        if (t + 1 < stages) stash(cur ^ 1);
+    }
+    const float mo = __shfl_xor(m, 32), lo = __shfl_xor(l, 32);
+    const float mm = fmaxf(m, mo);
+    const float a0 = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mm), a1 = mo == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mo - mm);
+    const float inv = 1.0f / (l * a0 + lo * a1);
+    float res[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) res[d] = (o[d] * a0 + __shfl_xor(o[d], 32) * a1) * inv;
+    if (live && h == 0) {
+        float *dst = out + qrow * (size_t)(heads * HD) + head * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) *reinterpret_cast<float4 *>(dst + d) = make_float4(res[d], res[d + 1], res[d + 2], res[d + 3]);
+    }
+}
+
 // ---- stats: L (log2 domain) and D = dO . O per (batch, head, query) ----
 template <int HD>
 __global__ __launch_bounds__(64 * WAVES) void attention_stats_kernel(int nq, int nk, int heads, const float *__restrict__ q, int qs, const float *__restrict__ k,
@@ -122,9 +249,10 @@ __global__ __launch_bounds__(64 * WAVES) void attention_stats_kernel(int nq, int
 }
 
 // ---- dq: query-stationary ----
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(64 * WAVES, 2) void attention_dq_kernel(int nq, int nk, int heads, const float *__restrict__ q, int qs, const float *__restrict__ k,
                                                                   int ks, const float *__restrict__ v, int vs, float scale_log2e, float scale,
+                                                                  uint32_t seed, uint32_t threshold, float inv_keep,
                                                                   const float *__restrict__ gout, const float *__restrict__ lse,
                                                                   const float *__restrict__ dsum, float *__restrict__ dq) {
     constexpr int KS = HD + 1;
@@ -142,6 +270,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attention_dq_kernel(int nq, int
     const float *grow = gout + qrow * (size_t)(heads * HD) + head * HD;
     const size_t so = ((size_t)bf * heads + head) * nq + (live ? qi : 0);
     const float L = lse[so], D = dsum[so];
+    const uint32_t drow = (uint32_t)(((size_t)bf * heads + head) * nq + qi);
     float qf[HD / 2], gf[HD / 2];
 #pragma unroll
     for (int s = 0; s < HD / 2; ++s) {
@@ -199,7 +328,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attention_dq_kernel(int nq, int
                 const int key = sub * 32 + chan_of(r, h);
                 float p = __builtin_amdgcn_exp2f(acc[r] - L);
                 if (kbase + chan_of(r, h) >= nk) p = 0.f;
-                float ds = p * (accp[r] - D);
+                const float mk = DROP ? drop_scale(seed, drow, (uint32_t)(kbase + chan_of(r, h)), threshold, inv_keep) : 1.0f;
+                float ds = p * (mk * accp[r] - D);
                 int off = key * HD;
                 asm volatile("" : "+v"(off), "+v"(ds));
                 const float *kr = &kp[cur][off];
@@ -227,9 +357,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attention_dq_kernel(int nq, int
 }
 
 // ---- dkv: key-stationary; writes dK | dV into a (BF, Nk, 2 heads HD) tensor laid out like the forward's kv ----
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(64 * WAVES, 2) void attention_dkv_kernel(int nq, int nk, int heads, const float *__restrict__ q, int qs, const float *__restrict__ k,
                                                                    int ks, const float *__restrict__ v, int vs, float scale_log2e, float scale,
+                                                                   uint32_t seed, uint32_t threshold, float inv_keep,
                                                                    const float *__restrict__ gout, const float *__restrict__ lse,
                                                                    const float *__restrict__ dsum, float *__restrict__ dkv) {
     constexpr int KS = HD + 1;
@@ -248,6 +379,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attention_dkv_kernel(int nq, in
     gout += (size_t)bf * nq * (size_t)(heads * HD) + head * HD;
     lse += ((size_t)bf * heads + head) * nq;
     dsum += ((size_t)bf * heads + head) * nq;
+    const uint32_t rbase = (uint32_t)(((size_t)bf * heads + head) * nq);
     float kf[HD / 2], vf[HD / 2];
 #pragma unroll
     for (int s = 0; s < HD / 2; ++s) {
@@ -313,7 +445,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attention_dkv_kernel(int nq, in
             for (int r = 0; r < 16; ++r) {
                 const int qq = sub * 32 + chan_of(r, h);
                 const float p = __builtin_amdgcn_exp2f(acc[r] - lt[cur][qq]);
-                float ds = p * (accp[r] - dt[cur][qq]);
+                const float mk = DROP ? drop_scale(seed, rbase + (uint32_t)(t * KT + qq), (uint32_t)ki, threshold, inv_keep) : 1.0f;
+                const float pm = DROP ? p * mk : p;
+                float ds = p * (mk * accp[r] - dt[cur][qq]);
                 int off = qq * HD;
                 asm volatile("" : "+v"(off), "+v"(ds));
                 const float *qr = &qp[cur][off], *gr = &gp[cur][off];
@@ -324,10 +458,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attention_dkv_kernel(int nq, in
                     acc_k[d + 1] = __builtin_fmaf(ds, qv.y, acc_k[d + 1]);
                     acc_k[d + 2] = __builtin_fmaf(ds, qv.z, acc_k[d + 2]);
                     acc_k[d + 3] = __builtin_fmaf(ds, qv.w, acc_k[d + 3]);
-                    acc_v[d + 0] = __builtin_fmaf(p, gv.x, acc_v[d + 0]);
-                    acc_v[d + 1] = __builtin_fmaf(p, gv.y, acc_v[d + 1]);
-                    acc_v[d + 2] = __builtin_fmaf(p, gv.z, acc_v[d + 2]);
-                    acc_v[d + 3] = __builtin_fmaf(p, gv.w, acc_v[d + 3]);
+                    acc_v[d + 0] = __builtin_fmaf(pm, gv.x, acc_v[d + 0]);
+                    acc_v[d + 1] = __builtin_fmaf(pm, gv.y, acc_v[d + 1]);
+                    acc_v[d + 2] = __builtin_fmaf(pm, gv.z, acc_v[d + 2]);
+                    acc_v[d + 3] = __builtin_fmaf(pm, gv.w, acc_v[d + 3]);
                 }
                 pin(acc_k);
                 pin(acc_v);
@@ -351,15 +485,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attention_dkv_kernel(int nq, in
     }
 }
 
-template <int HD>
-int launch_all(int bf, int nq, int nk, int heads, const float *q, int qs, const float *k, int ks, const float *v, int vs, float scale, const float *out,
-               const float *gout, float *dq, float *dkv, float *lse, float *dsum, hipStream_t s) {
+template <int HD, bool DROP>
+int launch_all(int bf, int nq, int nk, int heads, const float *q, int qs, const float *k, int ks, const float *v, int vs, float scale, uint32_t seed,
+               uint32_t threshold, float inv_keep, const float *out, const float *gout, float *dq, float *dkv, float *lse, float *dsum, hipStream_t s) {
     const float sl2 = scale * 1.44269504088896340736f;
     const dim3 gq(mcp_divup(nq, 32 * WAVES), heads, bf), gk(mcp_divup(nk, 32 * WAVES), heads, bf);
     hipLaunchKernelGGL(attention_stats_kernel<HD>, gq, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, sl2, out, gout, lse, dsum);
-    hipLaunchKernelGGL(attention_dq_kernel<HD>, gq, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, v, vs, sl2, scale, gout, lse, dsum, dq);
-    hipLaunchKernelGGL(attention_dkv_kernel<HD>, gk, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, v, vs, sl2, scale, gout, lse, dsum, dkv);
+    hipLaunchKernelGGL((attention_dq_kernel<HD, DROP>), gq, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, v, vs, sl2, scale, seed, threshold, inv_keep,
+                       gout, lse, dsum, dq);
+    hipLaunchKernelGGL((attention_dkv_kernel<HD, DROP>), gk, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, v, vs, sl2, scale, seed, threshold, inv_keep,
+                       gout, lse, dsum, dkv);
     return mcp_launch_status();
+}
+
+// drop probability -> (threshold of the 32-bit hash below which an entry is dropped, 1 / (1 - p))
+bool drop_params(float drop_p, uint32_t *threshold, float *inv_keep) {
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return false;
+    *threshold = (uint32_t)((double)drop_p * 4294967296.0);
+    *inv_keep = (float)(1.0 / (1.0 - (double)drop_p));
+    return true;
 }
 
 }  // namespace
@@ -369,19 +513,48 @@ MCP_EXPORT size_t mcp_attention_small_grad_workspace_bytes(int bf, int nq, int h
     return (size_t)2 * bf * heads * nq * sizeof(float);
 }
 
+MCP_EXPORT int mcp_attention_small_dropout(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
+                                           const float *v, int v_stride, float scale, float drop_p, unsigned seed, float *out, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(bf > 0 && nq > 0 && nk > 0 && heads > 0 && q && k && v && out);
+    if (hd != 8 && hd != 16) return MCP_ERR_UNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return MCP_ERR_BAD_ARG;
+    if ((q_stride | k_stride | v_stride) & 3) return MCP_ERR_BAD_ARG;
+    uint32_t threshold;
+    float inv_keep;
+    if (!drop_params(drop_p, &threshold, &inv_keep)) return MCP_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const dim3 grid(mcp_divup(nq, 32 * WAVES), heads, bf);
+    mcp_prof_begin(MCP_KERNEL_ATTENTION, s);
+    if (hd == 8)
+        hipLaunchKernelGGL(attention_small_drop_kernel<8>, grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, seed, threshold,
+                           inv_keep, out);
+    else
+        hipLaunchKernelGGL(attention_small_drop_kernel<16>, grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, seed, threshold,
+                           inv_keep, out);
+    mcp_prof_end(MCP_KERNEL_ATTENTION, s);
+    return mcp_launch_status();
+}
+
 MCP_EXPORT int mcp_attention_small_grad(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
-                                        int v_stride, float scale, const float *out, const float *grad_out, float *grad_q, float *grad_kv, void *workspace,
-                                        size_t workspace_bytes, mcp_stream_t stream) {
+                                        int v_stride, float scale, float drop_p, unsigned seed, const float *out, const float *grad_out, float *grad_q,
+                                        float *grad_kv, void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(bf > 0 && nq > 0 && nk > 0 && heads > 0 && q && k && v && out && grad_out && grad_q && grad_kv && workspace);
     if (hd != 8 && hd != 16) return MCP_ERR_UNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)grad_out | (uintptr_t)grad_q | (uintptr_t)grad_kv) & 15) return MCP_ERR_BAD_ARG;
     if ((q_stride | k_stride | v_stride) & 3) return MCP_ERR_BAD_ARG;
     if (workspace_bytes < mcp_attention_small_grad_workspace_bytes(bf, nq, heads)) return MCP_ERR_BAD_ARG;
+    uint32_t threshold;
+    float inv_keep;
+    if (!drop_params(drop_p, &threshold, &inv_keep)) return MCP_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     float *lse = static_cast<float *>(workspace), *dsum = lse + (size_t)bf * heads * nq;
     mcp_prof_begin(MCP_KERNEL_ATTENTION, s);
-    const int rc = hd == 8 ? launch_all<8>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, scale, out, grad_out, grad_q, grad_kv, lse, dsum, s)
-                           : launch_all<16>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, scale, out, grad_out, grad_q, grad_kv, lse, dsum, s);
+    int rc;
+#define MCP_ATT_ARGS bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, scale, seed, threshold, inv_keep, out, grad_out, grad_q, grad_kv, lse, dsum, s
+    if (drop_p > 0.f) rc = hd == 8 ? launch_all<8, true>(MCP_ATT_ARGS) : launch_all<16, true>(MCP_ATT_ARGS);
+    else rc = hd == 8 ? launch_all<8, false>(MCP_ATT_ARGS) : launch_all<16, false>(MCP_ATT_ARGS);
+#undef MCP_ATT_ARGS
     mcp_prof_end(MCP_KERNEL_ATTENTION, s);
     return rc;
 }

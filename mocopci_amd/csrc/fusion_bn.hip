@@ -241,14 +241,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_fwd_kernel(long long 
 }
 
 // mean = b + S1 / R, var = S2 / R - (S1 / R)^2 (biased), rstd = 1 / sqrt(var + eps): written into the bn vector; var also to var_out
-__global__ __launch_bounds__(128) void fusion_bn_stats_kernel(const float *__restrict__ partial, int parts, int c, double rows, const float *__restrict__ bias,
+__global__ __launch_bounds__(256) void fusion_bn_stats_kernel(const float *__restrict__ partial, int parts, int c, double rows, const float *__restrict__ bias,
                                                              float eps, float *__restrict__ bn_layer, float *__restrict__ var_out) {
-    const int e = threadIdx.x;
-    if (e >= c) return;
-    float a = 0.f, b = 0.f;
-    for (int g = 0; g < parts; ++g) {
-        a += partial[(size_t)g * 2 * c + e];
-        b += partial[(size_t)g * 2 * c + c + e];
+    // 16 channels per block, 16 chains per channel (workgroups ch, ch + 16, ... in order), chains added in chain order
+    __shared__ float ca[16][17], cb[16][17];
+    const int el = threadIdx.x & 15, ch = threadIdx.x >> 4, e = blockIdx.x * 16 + el;
+    float sa = 0.f, sb = 0.f;
+    if (e < c)
+        for (int g = ch; g < parts; g += 16) {
+            sa += partial[(size_t)g * 2 * c + e];
+            sb += partial[(size_t)g * 2 * c + c + e];
+        }
+    ca[ch][el] = sa;
+    cb[ch][el] = sb;
+    __syncthreads();
+    if (ch != 0 || e >= c) return;
+    float a = ca[0][el], b = cb[0][el];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        a += ca[i][el];
+        b += cb[i][el];
     }
     const double m = (double)a / rows;
     double var = (double)b / rows - m * m;
@@ -980,12 +992,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b4_kernel(long long t
 }
 
 // out[e] = sum over the workgroups' partial vectors, in workgroup order
+// 16 elements per block, 16 threads per element: thread c of an element adds the workgroups c, c + 16, ... in order, the 16 chains are
+// then added in chain order -- a fixed order again, and 16 dependent loads deep instead of `parts`.
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ partial, int parts, int stride, int count, float *__restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
+    __shared__ float chains[16][17];
+    const int el = threadIdx.x & 15, c = threadIdx.x >> 4, e = blockIdx.x * 16 + el;
     float s = 0.f;
-    for (int g = 0; g < parts; ++g) s += partial[(size_t)g * stride + e];
-    out[e] = s;
+    if (e < count)
+        for (int g = c; g < parts; g += 16) s += partial[(size_t)g * stride + e];
+    chains[c][el] = s;
+    __syncthreads();
+    if (c == 0 && e < count) {
+        float t = chains[0][el];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t += chains[i][el];
+        out[e] = t;
+    }
 }
 
 unsigned bwd_grid(long long total, int per_cu) {
@@ -1027,13 +1049,13 @@ MCP_EXPORT int mcp_fusion_bn_forward(int b, int n, int nb, const float *p1, cons
     mcp_prof_begin(MCP_KERNEL_FUSION, s);
     int rc = launch_fwd<1>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, partial, grid, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(fusion_bn_stats_kernel, dim3(1), dim3(128), 0, s, partial, (int)grid, C1, rows, b1, eps, bn + BN_L1, var);
+    hipLaunchKernelGGL(fusion_bn_stats_kernel, dim3(C1 / 16), dim3(256), 0, s, partial, (int)grid, C1, rows, b1, eps, bn + BN_L1, var);
     rc = launch_fwd<2>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, partial, grid, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(fusion_bn_stats_kernel, dim3(1), dim3(128), 0, s, partial, (int)grid, C2, rows, b2, eps, bn + BN_L2, var + C1);
+    hipLaunchKernelGGL(fusion_bn_stats_kernel, dim3(C2 / 16), dim3(256), 0, s, partial, (int)grid, C2, rows, b2, eps, bn + BN_L2, var + C1);
     rc = launch_fwd<3>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, partial, grid, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(fusion_bn_stats_kernel, dim3(1), dim3(128), 0, s, partial, (int)grid, C3, rows, b3, eps, bn + BN_L3, var + C1 + C2);
+    hipLaunchKernelGGL(fusion_bn_stats_kernel, dim3(C3 / 16), dim3(256), 0, s, partial, (int)grid, C3, rows, b3, eps, bn + BN_L3, var + C1 + C2);
     rc = launch_fwd<0>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, out, grid, s);
     mcp_prof_end(MCP_KERNEL_FUSION, s);
     return rc;
@@ -1086,27 +1108,27 @@ MCP_EXPORT int mcp_fusion_bn_backward(int b, int n, int nb, const float *p1, con
         const size_t lds = (size_t)L_F32 * 4 + (size_t)(W2_U4 + W3_U4) * 16 + (size_t)WAVES * B1_SCR * 4;
         hipLaunchKernelGGL(fusion_bn_b1_kernel, dim3(grid), dim3(64 * WAVES), lds, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, grad_out, row_c,
                            row_dy, row_a, partial);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)grid, 256, 256, sums3);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(16), dim3(256), 0, s, partial, (int)grid, 256, 256, sums3);
     }
     {   // B2
         const unsigned grid = bwd_grid(total, 1);
         hipLaunchKernelGGL(fusion_bn_b2_kernel, dim3(grid), dim3(64 * WAVES), B2_LDS, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, sums3, inv_rows,
                            w3t, row_c, row_dy, dy2, partial);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((C3 * C2 + 255) / 256), dim3(256), 0, s, partial, (int)grid, B2_G, C3 * C2, grad_weights + G_W3);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial + C3 * C2, (int)grid, B2_G, 2 * C2, sums2);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(C3 * C2 / 16), dim3(256), 0, s, partial, (int)grid, B2_G, C3 * C2, grad_weights + G_W3);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(2 * C2 / 16), dim3(256), 0, s, partial + C3 * C2, (int)grid, B2_G, 2 * C2, sums2);
     }
     {   // B3
         const unsigned grid = bwd_grid(total, 1);
         hipLaunchKernelGGL(fusion_bn_b3_kernel, dim3(grid), dim3(64 * WAVES), B3_LDS, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, b3, bn, sums2, inv_rows, dy2,
                            dy1, partial);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((C2 * C1 + 255) / 256), dim3(256), 0, s, partial, (int)grid, B3_G, C2 * C1, grad_weights + G_W2);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial + C2 * C1, (int)grid, B3_G, 2 * C1, sums1);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(C2 * C1 / 16), dim3(256), 0, s, partial, (int)grid, B3_G, C2 * C1, grad_weights + G_W2);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(2 * C1 / 16), dim3(256), 0, s, partial + C2 * C1, (int)grid, B3_G, 2 * C1, sums1);
     }
     {   // B4
         const unsigned grid = bwd_grid(total, 2);
         hipLaunchKernelGGL(fusion_bn_b4_kernel, dim3(grid), dim3(64 * WAVES), B4_LDS, s, total, n, p1, p2, idx, idx2, w1, b1, b2, b3, bn, sums1, inv_rows, dy1,
                            row_a, grad_out, grad_p1, grad_nb, partial);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)grid, B4_G, B4_G, grad_weights + G_W1);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(B4_G / 16), dim3(256), 0, s, partial, (int)grid, B4_G, B4_G, grad_weights + G_W1);
     }
     // grad_affine: per layer dgamma (= sum dy' zhat) | dbeta (= sum dy')
     (void)hipMemcpyAsync(grad_affine + 0, sums1 + C1, C1 * sizeof(float), hipMemcpyDeviceToDevice, s);

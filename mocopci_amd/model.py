@@ -277,6 +277,10 @@ class MoCoPCI(nn.Module):
         BF, Nq, C = q.shape
         Nk, hd = kv.shape[1], C // heads
         sc = hd ** -0.5 if scale is None else scale
+        if q.is_cuda and self.SDPA_DROPOUT and hd in (8, 16):
+            # head widths 8 / 16: this repo's attention kernels with the mask generated inside (forward and backward regenerate it
+            # from one seed drawn from torch's generator); nothing of size heads x Nq x Nk exists
+            return ops.backend().attention(q, kv, heads, scale=sc, dropout_p=p)
         if q.is_cuda and self.SDPA_DROPOUT:
             # the library's fused attention draws the dropout mask inside the kernel (forward and backward from one counter-based
             # stream seeded by torch's generator): same distribution as softmax -> F.dropout -> matmul, nothing of size

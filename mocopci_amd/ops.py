@@ -182,10 +182,10 @@ class _AttentionSmallFn(torch.autograd.Function):
     """mcp_attention_small (head dims 8 / 16) with its hand-written backward (mcp_attention_small_grad: row statistics, dQ, dK/dV)."""
 
     @staticmethod
-    def forward(ctx, be, q, kv, heads, scale):
+    def forward(ctx, be, q, kv, heads, scale, drop_p, seed):
         q, kv = q.detach().contiguous(), kv.detach().contiguous()
-        out = be._attention(q, kv, heads, scale)
-        ctx.heads, ctx.scale = heads, scale
+        out = be._attention(q, kv, heads, scale, drop_p, seed)
+        ctx.heads, ctx.scale, ctx.drop_p, ctx.seed = heads, scale, drop_p, seed
         ctx.save_for_backward(q, kv, out)
         return out
 
@@ -200,8 +200,8 @@ class _AttentionSmallFn(torch.autograd.Function):
         need = lib.mcp_attention_small_grad_workspace_bytes(BF, Nq, heads)
         ws = torch.empty((need,), dtype=torch.uint8, device=q.device)
         _call("mcp_attention_small_grad", q, BF, Nq, Nk, heads, C // heads, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
-              float(ctx.scale), _lib.fptr(out), _lib.fptr(grad_out), _lib.fptr(dq), _lib.fptr(dkv), ws.data_ptr(), need)
-        return None, dq, dkv, None, None
+              float(ctx.scale), float(ctx.drop_p), int(ctx.seed), _lib.fptr(out), _lib.fptr(grad_out), _lib.fptr(dq), _lib.fptr(dkv), ws.data_ptr(), need)
+        return None, dq, dkv, None, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -710,25 +710,38 @@ class HipBackend:
               float(slope), _lib.fptr(out))
         return out
 
-    def attention(self, q, kv, heads, scale=None):
+    def attention(self, q, kv, heads, scale=None, dropout_p=0.0):
         """softmax(q k^T * scale) v per head, reading the projection outputs in place: q (BF,Nq,C), kv (BF,Nk,2C)
-        laid out [k | v] as the reference's kv Linear produces (mocopci.py:74-75, :653-654) -> (BF,Nq,C)."""
+        laid out [k | v] as the reference's kv Linear produces (mocopci.py:74-75, :653-654) -> (BF,Nq,C).  dropout_p > 0 (head dims 8 /
+        16 only): attention dropout on the softmax matrix inside the kernel, the mask a counter-based hash seeded from torch's CPU
+        generator (reproducible under torch.manual_seed; see mcp_attention_small_dropout)."""
         BF, Nq, C = q.shape
         Nk = kv.shape[1]
         hd = C // heads
         if scale is None:
             scale = hd ** -0.5
+        if dropout_p > 0.0:
+            if hd not in (8, 16):
+                raise RuntimeError("attention dropout inside the kernel: head dims 8 / 16")
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())  # CPU generator: no device synchronisation
+            if grad.wants_grad(q, kv):
+                return _AttentionSmallFn.apply(self, q, kv, heads, float(scale), float(dropout_p), seed)
+            return self._attention(q, kv, heads, float(scale), float(dropout_p), seed)
         if hd not in (8, 16, 32, 64, 256):  # head dims neither kernel is built for: the dense formulation (same arithmetic as the twin)
             return grad.attention_twin(q, kv, heads, float(scale))
         if hd in (8, 16) and grad.wants_grad(q, kv):
-            return _AttentionSmallFn.apply(self, q, kv, heads, float(scale))
+            return _AttentionSmallFn.apply(self, q, kv, heads, float(scale), 0.0, 0)
         return grad.run(self._attention, grad.attention_twin, q, kv, heads, float(scale))
 
-    def _attention(self, q, kv, heads, scale):
+    def _attention(self, q, kv, heads, scale, drop_p=0.0, seed=0):
         q, kv = q.contiguous(), kv.contiguous()
         BF, Nq, C = q.shape
         Nk, hd = kv.shape[1], C // heads
         out = torch.empty((BF, Nq, C), dtype=torch.float32, device=q.device)
+        if drop_p > 0.0:
+            _call("mcp_attention_small_dropout", q, BF, Nq, Nk, heads, hd, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
+                  float(scale), float(drop_p), int(seed), out.data_ptr())
+            return out
         # head dims 8/16: S on MFMA, P.V on packed FMAs; 32/64/256 (ei3, Cross_Frame_Att): both products on MFMA
         name = "mcp_attention_small" if hd in (8, 16) else "mcp_attention_wide"
         _call(name, q, BF, Nq, Nk, heads, hd, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
