@@ -15,14 +15,14 @@
 //   Weight gradients accumulate in registers over a wave's points; waves are added in wave order through LDS, workgroups in
 //   workgroup order by a second kernel: every sum has a fixed order, the gradients repeat bit for bit.
 #include "common.h"
-#include "mfma_split.h"
+#include "mfma_grad.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KNB = 32;
 constexpr float SLOPE = 0.1f;  // pointconv_util.py:10
-constexpr int TS = 36;         // row stride (floats) of the transposition tile
+constexpr int TS = MCP_TS;
 
 __device__ __forceinline__ int chan_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ float leaky(float v) { return mcp_max_raw(v, v * SLOPE); }  // as the forward (cross.hip)
@@ -71,44 +71,8 @@ struct GradShape {
     static_assert((size_t)G_FLOATS * 4 <= (size_t)L_F32 * 4 + (size_t)W_LDS_U4 * 16, "the reduction buffer overlays the weight images");
 };
 
-__device__ __forceinline__ void split_weights_transposed(uint4 *dst, const float *__restrict__ w, int m_total, int k_total, int first, int stride) {
-    const int ksteps = k_total / 16, out_tiles = m_total / 32;  // image of A[m][k] = w[k * m_total + m]
-    for (int e = first; e < out_tiles * ksteps * 64; e += stride) {
-        const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = w[(size_t)(32 * (s >> 1) + mcp_chan_of(8 * (s & 1) + i, lane >> 5)) * m_total + 32 * t + (lane & 31)];
-        const McpSplit3 sp = mcp_split8(v);
-        uint4 *o = dst + (size_t)(t * ksteps + s) * 3 * 64 + lane;
-        o[0] = sp.p1;
-        o[64] = sp.p2;
-        o[128] = sp.p3;
-    }
-}
 __global__ __launch_bounds__(256) void transposed_image_kernel(uint4 *dst, const float *__restrict__ w, int d) {
-    split_weights_transposed(dst, w, d, d, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
-}
-
-__device__ __forceinline__ void read8(const float *row, float *v) {
-    const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-// two accumulator-layout tiles (64 channels x 32 neighbours) into the tile buffer: row = channel, column = neighbour
-__device__ __forceinline__ void write_pair(float *tb, const f32x16 &a, const f32x16 &b, int col, int h) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        tb[chan_of(r, h) * TS + col] = a[r];
-        tb[(32 + chan_of(r, h)) * TS + col] = b[r];
-    }
-}
-__device__ __forceinline__ f32x16 mfma_split6(const McpSplit3 &a, const McpSplit3 &b, f32x16 acc) {
-    acc = mcp_mfma_bf16(a.p3, b.p1, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p3, acc);
-    acc = mcp_mfma_bf16(a.p2, b.p2, acc);
-    acc = mcp_mfma_bf16(a.p2, b.p1, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p2, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p1, acc);
-    return acc;
+    mcp_split_weights_transposed(dst, w, d, d, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // One workgroup of a role: points first, first + step, ... of the launch.  DATA: dx, the per-neighbour outputs, dWpos;
@@ -146,7 +110,7 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
         lds[S::L_B + e] = bmlp[32 * t + chan_of(r, hh)];
     }
     mcp_split_weights(wms, wmlp, D, T, tid, 64 * WAVES);
-    if (S::WT_LDS) split_weights_transposed(wmts_lds, wmlp, D, D, tid, 64 * WAVES);
+    if (S::WT_LDS) mcp_split_weights_transposed(wmts_lds, wmlp, D, D, tid, 64 * WAVES);
     __syncthreads();
 
     f32x16 dWa[2][HAS_OWN ? T : 1];  // dWmlp tiles: row = 32 (OWN + a) + chan_of(r, h), column = 32 nt + col
@@ -251,7 +215,7 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             float v[8];
-                            read8(tb + (32 * a + col) * TS + 16 * ks + 8 * h, v);
+                            mcp_read8(tb + (32 * a + col) * TS + 16 * ks + 8 * h, v);
                             dbm[a] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                             as[a][ks] = mcp_split8(v);
                         }
@@ -263,17 +227,18 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
 #pragma unroll
         for (int hb = 0; hb < (HAS_OWN ? T / 2 : 0); ++hb) {
             __builtin_amdgcn_wave_barrier();
-            write_pair(tb, x[2 * hb], x[2 * hb + 1], col, h);
+            mcp_write_tile(tb, x[2 * hb], col, h);
+            mcp_write_tile(tb + 32 * TS, x[2 * hb + 1], col, h);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(tb + (32 * tt + col) * TS + 16 * ks + 8 * h, v);
+                    mcp_read8(tb + (32 * tt + col) * TS + 16 * ks + 8 * h, v);
                     const McpSplit3 bs = mcp_split8(v);
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) dWa[a][HAS_OWN ? 2 * hb + tt : 0] = mfma_split6(as[a][ks], bs, dWa[a][HAS_OWN ? 2 * hb + tt : 0]);
+                    for (int a = 0; a < 2; ++a) dWa[a][HAS_OWN ? 2 * hb + tt : 0] = mcp_mfma_split6(as[a][ks], bs, dWa[a][HAS_OWN ? 2 * hb + tt : 0]);
                 }
         }
         if (DATA) {
@@ -315,7 +280,8 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
 #pragma unroll
             for (int hb = 0; hb < T / 2; ++hb) {
                 __builtin_amdgcn_wave_barrier();
-                write_pair(tb, du[DATA ? 2 * hb : 0], du[DATA ? 2 * hb + 1 : 0], col, h);
+                mcp_write_tile(tb, du[DATA ? 2 * hb : 0], col, h);
+            mcp_write_tile(tb + 32 * TS, du[DATA ? 2 * hb + 1 : 0], col, h);
                 if (hb == 0 && h == 0) dirb[col] = make_float4(dx, dy, dzc, 0.f);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -325,7 +291,7 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         float v[8];
-                        read8(tb + (32 * tt + col) * TS + 16 * ks + 8 * h, v);
+                        mcp_read8(tb + (32 * tt + col) * TS + 16 * ks + 8 * h, v);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const float4 dj = dirb[16 * ks + 8 * h + i];

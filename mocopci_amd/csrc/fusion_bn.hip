@@ -14,7 +14,7 @@
 // Every per-channel sum is per-lane over a wave's points, then a fixed butterfly, waves in wave order, workgroups in workgroup
 // order: results repeat bit for bit.  All kernels of one call (one set of statistics) see only that call's clouds.
 #include "common.h"
-#include "mfma_split.h"
+#include "mfma_grad.h"
 
 namespace {
 
@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int C1 = 64, C2 = 64, C3 = 128, NB = 64;
 constexpr int WAVES = 4;
-constexpr int TS = 36;  // row stride (floats) of the transposition tile (backward passes)
+constexpr int TS = MCP_TS;
 // bn vector (floats, natural channel order): per layer mean | rstd | gamma | beta
 constexpr int BN_L1 = 0, BN_L2 = 4 * C1, BN_L3 = 4 * C1 + 4 * C2, BN_FLOATS = BN_L3 + 4 * C3;  // 1024
 
@@ -292,45 +292,8 @@ int launch_fwd(long long total, int n, const float *p1, const float *p2, const i
     return mcp_launch_status();
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// backward passes
-// ---------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split_weights_transposed(uint4 *dst, const float *__restrict__ w, int m_total, int k_total, int first, int stride) {
-    const int ksteps = k_total / 16, out_tiles = m_total / 32;  // image of A[m][k] = w[k * m_total + m]
-    for (int e = first; e < out_tiles * ksteps * 64; e += stride) {
-        const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = w[(size_t)(32 * (s >> 1) + mcp_chan_of(8 * (s & 1) + i, lane >> 5)) * m_total + 32 * t + (lane & 31)];
-        const McpSplit3 sp = mcp_split8(v);
-        uint4 *o = dst + (size_t)(t * ksteps + s) * 3 * 64 + lane;
-        o[0] = sp.p1;
-        o[64] = sp.p2;
-        o[128] = sp.p3;
-    }
-}
 __global__ __launch_bounds__(256) void transposed_image_kernel(uint4 *dst, const float *__restrict__ w, int m_total, int k_total) {
-    split_weights_transposed(dst, w, m_total, k_total, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
-}
-__device__ __forceinline__ void read8(const float *row, float *v) {
-    const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-__device__ __forceinline__ float sum8(const float *v) { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
-// one accumulator-layout tile (32 channels x 32 neighbours) into rows 0..31 of a tile buffer: row = channel, column = neighbour
-__device__ __forceinline__ void write_tile(float *tb, const f32x16 &v, int col, int h) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tb[chan_of(r, h) * TS + col] = v[r];
-}
-__device__ __forceinline__ f32x16 mfma_split6(const McpSplit3 &a, const McpSplit3 &b, f32x16 acc) {
-    acc = mcp_mfma_bf16(a.p3, b.p1, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p3, acc);
-    acc = mcp_mfma_bf16(a.p2, b.p2, acc);
-    acc = mcp_mfma_bf16(a.p2, b.p1, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p2, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p1, acc);
-    return acc;
+    mcp_split_weights_transposed(dst, w, m_total, k_total, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 // per-channel constants of dz = a dy' - c1 - zhat c2 in accumulator order: a = gamma rstd, c1 = a sum(dy') / R, c2 = a sum(dy' zhat) / R
 __device__ __forceinline__ void stage_dz_consts(float *dst, const float *__restrict__ bn_layer, const float *__restrict__ sums, int c, float inv_rows, int tid,
@@ -370,26 +333,26 @@ __device__ __forceinline__ void store_row64(float *row, int h, const f32x16 *v) 
 __device__ __forceinline__ void channel_sums(float *tb, const f32x16 *dy, const f32x16 *zhat, int col, int h, float *sums, float *sumz) {
     float dyv[2][2][8];
     __builtin_amdgcn_wave_barrier();
-    write_tile(tb, dy[0], col, h);
-    write_tile(tb + 32 * TS, dy[1], col, h);
+    mcp_write_tile(tb, dy[0], col, h);
+    mcp_write_tile(tb + 32 * TS, dy[1], col, h);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, dyv[mt][ks]);
-            sums[mt] += sum8(dyv[mt][ks]);
+            mcp_read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, dyv[mt][ks]);
+            sums[mt] += mcp_sum8(dyv[mt][ks]);
         }
     __builtin_amdgcn_wave_barrier();
-    write_tile(tb, zhat[0], col, h);
-    write_tile(tb + 32 * TS, zhat[1], col, h);
+    mcp_write_tile(tb, zhat[0], col, h);
+    mcp_write_tile(tb + 32 * TS, zhat[1], col, h);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float zv[8];
-            read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, zv);
+            mcp_read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, zv);
             float a = dyv[mt][ks][0] * zv[0];
 #pragma unroll
             for (int i = 1; i < 8; ++i) a = __builtin_fmaf(dyv[mt][ks][i], zv[i], a);
@@ -508,8 +471,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b1_kernel(long long t
                 const int4 ca = reinterpret_cast<const int4 *>(csb + j0)[0], cb = reinterpret_cast<const int4 *>(csb + j0)[1];
                 const int cs8[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
                 float dz8[8], ez8[8];
-                read8(dzb + j0, dz8);
-                read8(ezb + j0, ez8);
+                mcp_read8(dzb + j0, dz8);
+                mcp_read8(ezb + j0, ez8);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int c = 32 * mt + col;
@@ -622,7 +585,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b2_kernel(long long t
                     }
                     x2[2 * t + 0] = mcp_split_kstep(v, 0);
                     x2[2 * t + 1] = mcp_split_kstep(v, 1);
-                    write_tile(tb + 32 * t * TS, v, col, h);  // y2^T: the B operand of dW3
+                    mcp_write_tile(tb + 32 * t * TS, v, col, h);  // y2^T: the B operand of dW3
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -630,12 +593,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b2_kernel(long long t
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         float v[8];
-                        read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
+                        mcp_read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
                         bs[nt][ks] = mcp_split8(v);
                     }
                 __builtin_amdgcn_wave_barrier();
-                write_tile(tb, zh2[0], col, h);  // zhat2^T stays in the tile until the sums at the end of the half
-                write_tile(tb + 32 * TS, zh2[1], col, h);
+                mcp_write_tile(tb, zh2[0], col, h);  // zhat2^T stays in the tile until the sums at the end of the half
+                mcp_write_tile(tb + 32 * TS, zh2[1], col, h);
             }
             f32x16 dh2[2];
 #pragma unroll
@@ -653,15 +616,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b2_kernel(long long t
                 for (int r = 0; r < 16; ++r) dy[r] = (32 * t + chan_of(r, h)) == cst ? dys : 0.f;
                 dz_tile<C3>(lds + B2_L_DZ + (t * 2 + h) * 16, dy, zh, dz);
                 __builtin_amdgcn_wave_barrier();
-                write_tile(tz, dz, col, h);
+                mcp_write_tile(tz, dz, col, h);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v8[8];
-                    read8(tz + col * TS + 16 * ks + 8 * h, v8);
+                    mcp_read8(tz + col * TS + 16 * ks + 8 * h, v8);
                     const McpSplit3 as = mcp_split8(v8);
-                    dW3a[t][0] = mfma_split6(as, bs[0][ks], dW3a[t][0]);
-                    dW3a[t][1] = mfma_split6(as, bs[1][ks], dW3a[t][1]);
+                    dW3a[t][0] = mcp_mfma_split6(as, bs[0][ks], dW3a[t][0]);
+                    dW3a[t][1] = mcp_mfma_split6(as, bs[1][ks], dW3a[t][1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const McpSplit3 z0 = mcp_split_kstep(dz, 0), z1s = mcp_split_kstep(dz, 1);
@@ -682,14 +645,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b2_kernel(long long t
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 __builtin_amdgcn_wave_barrier();
-                write_tile(tz, dh2[mt], col, h);
+                mcp_write_tile(tz, dh2[mt], col, h);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float dv[8], zv[8];
-                    read8(tz + col * TS + 16 * ks + 8 * h, dv);
-                    read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, zv);
-                    s2[mt] += sum8(dv);
+                    mcp_read8(tz + col * TS + 16 * ks + 8 * h, dv);
+                    mcp_read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, zv);
+                    s2[mt] += mcp_sum8(dv);
                     float a = dv[0] * zv[0];
 #pragma unroll
                     for (int i = 1; i < 8; ++i) a = __builtin_fmaf(dv[i], zv[i], a);
@@ -745,7 +708,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b3_kernel(long long t
     stage_f32(lds, w1, b1, b2, b3, bn, 2, tid, 64 * WAVES);
     stage_dz_consts(lds + B3_L_DZ, bn + BN_L2, sums2, C2, inv_rows, tid, 64 * WAVES);
     mcp_split_weights(w2s, w2, C1, 2, tid, 64 * WAVES);
-    split_weights_transposed(w2ts, w2, C1, C2, tid, 64 * WAVES);
+    mcp_split_weights_transposed(w2ts, w2, C1, C2, tid, 64 * WAVES);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     float *tb = reinterpret_cast<float *>(w2ts + W2_U4) + wave * B3_SCR;
@@ -796,8 +759,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b3_kernel(long long t
             }
             // dW2 += dz2 . y1^T
             __builtin_amdgcn_wave_barrier();
-            write_tile(tb, dz2[0], col, h);
-            write_tile(tb + 32 * TS, dz2[1], col, h);
+            mcp_write_tile(tb, dz2[0], col, h);
+            mcp_write_tile(tb + 32 * TS, dz2[1], col, h);
             __builtin_amdgcn_wave_barrier();
             McpSplit3 as[2][2];
 #pragma unroll
@@ -805,22 +768,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b3_kernel(long long t
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                    mcp_read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
                     as[mt][ks] = mcp_split8(v);
                 }
             __builtin_amdgcn_wave_barrier();
-            write_tile(tb, y1[0], col, h);
-            write_tile(tb + 32 * TS, y1[1], col, h);
+            mcp_write_tile(tb, y1[0], col, h);
+            mcp_write_tile(tb + 32 * TS, y1[1], col, h);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
+                    mcp_read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
                     const McpSplit3 bsp = mcp_split8(v);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) dW2a[mt][nt] = mfma_split6(as[mt][ks], bsp, dW2a[mt][nt]);
+                    for (int mt = 0; mt < 2; ++mt) dW2a[mt][nt] = mcp_mfma_split6(as[mt][ks], bsp, dW2a[mt][nt]);
                 }
             // dh1 = W2^T dz2; dy1' = dh1 [y1 > 0]
             f32x16 dh1[2];
@@ -921,8 +884,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b4_kernel(long long t
                 dz_tile<C1>(lds + B4_L_DZ + (t * 2 + h) * 16, dy[t], zh, dz1[t]);
             }
             __builtin_amdgcn_wave_barrier();
-            write_tile(tb, dz1[0], col, h);
-            write_tile(tb + 32 * TS, dz1[1], col, h);
+            mcp_write_tile(tb, dz1[0], col, h);
+            mcp_write_tile(tb + 32 * TS, dz1[1], col, h);
             if (h == 0) x0b[col] = make_float4(rx, ry, rz, dist);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -930,7 +893,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b4_kernel(long long t
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                    mcp_read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float4 xj = x0b[16 * ks + 8 * h + i];

@@ -20,7 +20,7 @@
 //   workgroups' partial vectors in workgroup order: every sum has a fixed order, so the gradients repeat bit for bit.
 //   Per point 672 bf16 MFMAs (forward: 288) + 16 f32 ones.
 #include "common.h"
-#include "mfma_split.h"
+#include "mfma_grad.h"
 
 namespace {
 
@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int C1 = 64, C2 = 64, C3 = 128, NB = 64;
 constexpr int WAVES = 4;
-constexpr int TS = 36;  // row stride (floats) of the transposition tile: 16-byte aligned rows, 8-float reads spread over the banks
+constexpr int TS = MCP_TS;
 
 // layout of the weight-gradient vector (floats): dW1 (64,4) | db1 | dW2 (64,64) | db2 | dW3 (128,64) | db3
 constexpr int G_W1 = 0, G_B1 = G_W1 + C1 * 4, G_W2 = G_B1 + C1, G_B2 = G_W2 + C2 * C1, G_W3 = G_B2 + C2, G_B3 = G_W3 + C3 * C2,
@@ -55,45 +55,6 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
-}
-
-// Image of A[m][k] = w[k * m_total + m] (the transpose of a row-major (k_total, m_total) matrix) in mcp_split_weights' layout.
-__device__ __forceinline__ void split_weights_transposed(uint4 *dst, const float *__restrict__ w, int m_total, int k_total, int first, int stride) {
-    const int ksteps = k_total / 16, out_tiles = m_total / 32;
-    for (int e = first; e < out_tiles * ksteps * 64; e += stride) {
-        const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = w[(size_t)(32 * (s >> 1) + mcp_chan_of(8 * (s & 1) + i, lane >> 5)) * m_total + 32 * t + (lane & 31)];
-        const McpSplit3 sp = mcp_split8(v);
-        uint4 *o = dst + (size_t)(t * ksteps + s) * 3 * 64 + lane;
-        o[0] = sp.p1;
-        o[64] = sp.p2;
-        o[128] = sp.p3;
-    }
-}
-
-// 8 consecutive neighbours of one channel row of the transposition tile
-__device__ __forceinline__ void read8(const float *row, float *v) {
-    const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-// accumulator-layout tiles (64 channels x 32 neighbours) into the tile buffer: row = channel, column = neighbour
-__device__ __forceinline__ void write_tiles(float *tb, const f32x16 *v, int col, int h) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tb[(32 * t + chan_of(r, h)) * TS + col] = v[t][r];
-}
-// acc += A . B with both operands split three ways (small terms first, as mcp_mfma_split)
-__device__ __forceinline__ f32x16 mfma_split6(const McpSplit3 &a, const McpSplit3 &b, f32x16 acc) {
-    acc = mcp_mfma_bf16(a.p3, b.p1, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p3, acc);
-    acc = mcp_mfma_bf16(a.p2, b.p2, acc);
-    acc = mcp_mfma_bf16(a.p2, b.p1, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p2, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p1, acc);
-    return acc;
 }
 
 __global__ __launch_bounds__(64 * WAVES, 1) void fusion_grad_kernel(long long total, int n, const float *__restrict__ p1, const float *__restrict__ p2,
@@ -123,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_grad_kernel(long long to
     }
     mcp_split_weights(w2s, w2, C1, 2, tid, 64 * WAVES);
     mcp_split_weights(w3s, w3, C2, 4, tid, 64 * WAVES);
-    split_weights_transposed(w2ts, w2, C1, C2, tid, 64 * WAVES);
+    mcp_split_weights_transposed(w2ts, w2, C1, C2, tid, 64 * WAVES);
     for (int e = tid; e < 64; e += 64 * WAVES) {  // biases: [t][h][r]
         const int r = e & 15, hh = (e >> 4) & 1, t = e >> 5;
         lds[L_B1 + e] = b1[32 * t + chan_of(r, hh)];
@@ -275,7 +236,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_grad_kernel(long long to
                 const int4 ca = reinterpret_cast<const int4 *>(csb + j0)[0], cb = reinterpret_cast<const int4 *>(csb + j0)[1];
                 const int cs8[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
                 float dz8[8];
-                read8(dzb + j0, dz8);
+                mcp_read8(dzb + j0, dz8);
                 uint4 oh[4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
@@ -292,7 +253,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_grad_kernel(long long to
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     float v[8];
-                    read8(tb + (32 * nt + col) * TS + j0, v);
+                    mcp_read8(tb + (32 * nt + col) * TS + j0, v);
                     const McpSplit3 bs = mcp_split8(v);
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
@@ -338,7 +299,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_grad_kernel(long long to
             }
             // ---- dW2 += dz2 . h1^T, db2 ----
             __builtin_amdgcn_wave_barrier();
-            write_tiles(tb, dz2, col, h);
+            mcp_write_tiles(tb, dz2, col, h);
             __builtin_amdgcn_wave_barrier();
             McpSplit3 as[2][2];
 #pragma unroll
@@ -346,33 +307,33 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_grad_kernel(long long to
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                    mcp_read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
                     db2a[mt] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                     as[mt][ks] = mcp_split8(v);
                 }
             __builtin_amdgcn_wave_barrier();
-            write_tiles(tb, h1, col, h);
+            mcp_write_tiles(tb, h1, col, h);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
+                    mcp_read8(tb + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
                     const McpSplit3 bs = mcp_split8(v);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) dW2a[mt][nt] = mfma_split6(as[mt][ks], bs, dW2a[mt][nt]);
+                    for (int mt = 0; mt < 2; ++mt) dW2a[mt][nt] = mcp_mfma_split6(as[mt][ks], bs, dW2a[mt][nt]);
                 }
             // ---- dW1 += dz1 . x0^T, db1 ----
             __builtin_amdgcn_wave_barrier();
-            write_tiles(tb, dz1, col, h);
+            mcp_write_tiles(tb, dz1, col, h);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                    mcp_read8(tb + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float4 xj = x0b[16 * ks + 8 * h + i];

@@ -13,13 +13,13 @@
 //     (B,N,16,64), dxyz_rows = -dd (B,N,16,3); dL/dq and the centre's share of dL/dxyz are written directly.
 // Waves are added in wave order through LDS, workgroups in workgroup order by a second kernel: bit-reproducible.
 #include "common.h"
-#include "mfma_split.h"
+#include "mfma_grad.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int C = 64, KNB = 16, WAVES = 4;
-constexpr int TS = 36;
+constexpr int TS = MCP_TS;
 // weight-gradient vector (floats): dWd1 (64,3) | dbd1 | dWd2 (64,64) | dbd2 | dWg1 (64,64) | dbg1 | dWg2 (64,64) | dbg2
 constexpr int G_WD1 = 0, G_BD1 = 192, G_WD2 = 256, G_BD2 = G_WD2 + 4096, G_WG1 = G_BD2 + 64, G_BG1 = G_WG1 + 4096, G_WG2 = G_BG1 + 64,
               G_BG2 = G_WG2 + 4096, G_FLOATS = G_BG2 + 64;  // 12736
@@ -50,47 +50,13 @@ __device__ __forceinline__ float row_sum(float v) {
     return v + dppf<0x140>(v);
 }
 
-__device__ __forceinline__ void split_weights_transposed(uint4 *dst, const float *__restrict__ w, int m_total, int k_total, int first, int stride) {
-    const int ksteps = k_total / 16, out_tiles = m_total / 32;  // image of A[m][k] = w[k * m_total + m]
-    for (int e = first; e < out_tiles * ksteps * 64; e += stride) {
-        const int lane = e & 63, s = (e >> 6) % ksteps, t = (e >> 6) / ksteps;
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = w[(size_t)(32 * (s >> 1) + mcp_chan_of(8 * (s & 1) + i, lane >> 5)) * m_total + 32 * t + (lane & 31)];
-        const McpSplit3 sp = mcp_split8(v);
-        uint4 *o = dst + (size_t)(t * ksteps + s) * 3 * 64 + lane;
-        o[0] = sp.p1;
-        o[64] = sp.p2;
-        o[128] = sp.p3;
-    }
-}
 // the three transposed images (Wd2^T | Wg1^T | Wg2^T) into the workspace
 __global__ __launch_bounds__(256) void ptblock_transposed_images_kernel(uint4 *dst, const float *__restrict__ wd2, const float *__restrict__ wg1,
                                                                         const float *__restrict__ wg2) {
     const float *w = blockIdx.y == 0 ? wd2 : blockIdx.y == 1 ? wg1 : wg2;
-    split_weights_transposed(dst + (size_t)blockIdx.y * W_U4, w, C, C, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+    mcp_split_weights_transposed(dst + (size_t)blockIdx.y * W_U4, w, C, C, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-__device__ __forceinline__ void read8(const float *row, float *v) {
-    const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-__device__ __forceinline__ float sum8(const float *v) { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
-__device__ __forceinline__ void write_tiles(float *tb, const f32x16 *v, int col, int h) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tb[(32 * t + chan_of(r, h)) * TS + col] = v[t][r];
-}
-__device__ __forceinline__ f32x16 mfma_split6(const McpSplit3 &a, const McpSplit3 &b, f32x16 acc) {
-    acc = mcp_mfma_bf16(a.p3, b.p1, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p3, acc);
-    acc = mcp_mfma_bf16(a.p2, b.p2, acc);
-    acc = mcp_mfma_bf16(a.p2, b.p1, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p2, acc);
-    acc = mcp_mfma_bf16(a.p1, b.p1, acc);
-    return acc;
-}
 // y = W x + b (64 -> 64) on accumulator-layout input, as the forward's layer64
 __device__ __forceinline__ void layer64(const uint4 *ws, const float *bias, int lane, int h, const f32x16 (&x)[2], f32x16 (&y)[2]) {
     McpSplit3 xs[4];
@@ -108,15 +74,15 @@ __device__ __forceinline__ void layer64(const uint4 *ws, const float *bias, int 
 __device__ __forceinline__ void weight_grad(float *ty, const float *tx, const f32x16 *dy, int col, int h, f32x16 (&dW)[2][2], float (&db)[2]) {
     McpSplit3 as[2][2];
     __builtin_amdgcn_wave_barrier();
-    write_tiles(ty, dy, col, h);
+    mcp_write_tiles(ty, dy, col, h);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float v[8];
-            read8(ty + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
-            db[mt] += sum8(v);
+            mcp_read8(ty + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+            db[mt] += mcp_sum8(v);
             as[mt][ks] = mcp_split8(v);
         }
 #pragma unroll
@@ -124,10 +90,10 @@ __device__ __forceinline__ void weight_grad(float *ty, const float *tx, const f3
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float v[8];
-            read8(tx + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
+            mcp_read8(tx + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
             const McpSplit3 bs = mcp_split8(v);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) dW[mt][nt] = mfma_split6(as[mt][ks], bs, dW[mt][nt]);
+            for (int mt = 0; mt < 2; ++mt) dW[mt][nt] = mcp_mfma_split6(as[mt][ks], bs, dW[mt][nt]);
         }
 }
 
@@ -238,8 +204,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void ptblock_grad_kernel(long long t
                 }
             layer64(wg2s, lds + L_BG2, lane, h, a1, attn);
             __builtin_amdgcn_wave_barrier();
-            write_tiles(ta, a1, col, h);  // a1^T: the B operand of dWg2
-            write_tiles(tb, g, col, h);   // g^T: the B operand of dWg1
+            mcp_write_tiles(ta, a1, col, h);  // a1^T: the B operand of dWg2
+            mcp_write_tiles(tb, g, col, h);   // g^T: the B operand of dWg1
             if (h == 0) dirb[col] = make_float4(dx, dy, dz, 0.f);
         }
         // ---------------- softmax over the 16 neighbours, backwards ----------------
@@ -278,22 +244,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void ptblock_grad_kernel(long long t
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(ta + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
+                    mcp_read8(ta + (32 * nt + col) * TS + 16 * ks + 8 * h, v);
                     bs[nt][ks] = mcp_split8(v);
                 }
             __builtin_amdgcn_wave_barrier();
-            write_tiles(ta, dattn, col, h);
+            mcp_write_tiles(ta, dattn, col, h);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(ta + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
-                    dbg2[mt] += sum8(v);
+                    mcp_read8(ta + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                    dbg2[mt] += mcp_sum8(v);
                     const McpSplit3 as = mcp_split8(v);
-                    dWg2a[mt][0] = mfma_split6(as, bs[0][ks], dWg2a[mt][0]);
-                    dWg2a[mt][1] = mfma_split6(as, bs[1][ks], dWg2a[mt][1]);
+                    dWg2a[mt][0] = mcp_mfma_split6(as, bs[0][ks], dWg2a[mt][0]);
+                    dWg2a[mt][1] = mcp_mfma_split6(as, bs[1][ks], dWg2a[mt][1]);
                 }
             f32x16 da1[2];
             layer64(wg2t, nullptr, lane, h, dattn, da1);
@@ -309,15 +275,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void ptblock_grad_kernel(long long t
             layer64(wg1t, nullptr, lane, h, dz1, dg);
             // dL/dq = sum_j dg_j: lane = channel over the transposed tile; a point's 16 neighbours are one k-step (two lane halves)
             __builtin_amdgcn_wave_barrier();
-            write_tiles(ta, dg, col, h);
+            mcp_write_tiles(ta, dg, col, h);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     float v[8];
-                    read8(ta + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
-                    float s = sum8(v);
+                    mcp_read8(ta + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                    float s = mcp_sum8(v);
                     s += __shfl_xor(s, 32);
                     const long long pq = 2 * pp + ks;
                     if (h == 0 && pq < total) d_q[pq * C + 32 * mt + col] = s;
@@ -346,7 +312,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void ptblock_grad_kernel(long long t
         f32x16 d1[2];
         first_layer(d1);
         __builtin_amdgcn_wave_barrier();
-        write_tiles(tb, d1, col, h);  // d1^T: the B operand of dWd2
+        mcp_write_tiles(tb, d1, col, h);  // d1^T: the B operand of dWd2
         weight_grad(ta, tb, ddelta, col, h, dWd2a, dbd2);
         f32x16 dzd[2];
         {
@@ -359,15 +325,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void ptblock_grad_kernel(long long t
         }
         // dWd1 += dzd . d^T, dbd1 (lane = channel); dd = Wd1^T dzd
         __builtin_amdgcn_wave_barrier();
-        write_tiles(ta, dzd, col, h);
+        mcp_write_tiles(ta, dzd, col, h);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 float v[8];
-                read8(ta + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
-                dbd1[mt] += sum8(v);
+                mcp_read8(ta + (32 * mt + col) * TS + 16 * ks + 8 * h, v);
+                dbd1[mt] += mcp_sum8(v);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float4 dj = dirb[16 * ks + 8 * h + i];
