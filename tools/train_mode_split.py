@@ -2,7 +2,7 @@
 (running-statistics) kernel pair -- timing only, the second variant is not the reference's training mode."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mocopci_amd import synth, training, ops
 from mocopci_amd.model import MoCoPCI
 B, N = 8, 8192
