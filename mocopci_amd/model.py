@@ -263,6 +263,8 @@ class MoCoPCI(nn.Module):
         keep = torch.empty(x.shape[:2] + (1,) * (x.dim() - 2), device=x.device, dtype=x.dtype).bernoulli_(1.0 - p)
         return x * (keep / (1.0 - p))
 
+    TRAIN_PYRAMID_LANE = True   # training forwards: the encoder's FPS chain on side lane 0, beside the level-0 layers
+    _train_lane0 = False
     SDPA_DROPOUT = True         # net.train() on the GPU: attention dropout inside the library's fused attention kernel
     CHECKPOINT_BYTES = 1 << 30  # net.train() forwards: unfused blocks whose intermediates exceed this are recomputed in the backward, in chunks of about this size
 
@@ -347,7 +349,9 @@ class MoCoPCI(nn.Module):
         features (schedule.NODE_LANES).  4: the level-0 self search.  5: the refinement stage's FPS (a lane of its own: the NEXT batch's
         pyramid may already be queued on lane 0).  One set per caller stream, so forwards issued on different streams stay
         independent.  CPU backends run inline."""
-        if device.type != "cuda" or self._live is not None:  # a training forward runs on one stream (autograd replays it in order)
+        # a training forward runs on one stream (autograd replays it in order) -- except lane 0: the sampling pyramid is a function of
+        # the input clouds alone and carries no gradient (TRAIN_PYRAMID_LANE; off when the inputs themselves ask for one)
+        if device.type != "cuda" or (self._live is not None and not (which == 0 and self._train_lane0)):
             return None
         if self.LANE_MAP is not None:
             which = self.LANE_MAP[which]
@@ -388,7 +392,7 @@ class MoCoPCI(nn.Module):
         if standalone:
             sched = Schedule(self, xyz.device)
         if speculate is None:
-            speculate = not sched.has("xyz") and sched.lane(("pc", 1)) is not None
+            speculate = self._live is None and not sched.has("xyz") and sched.lane(("pc", 1)) is not None   # inference only
         if not sched.has("xyz"):
             self.issue_inputs_only(sched, lambda: xyz)
         pc = lambda lvl: sched.get(("pc", lvl))[0]
@@ -1385,6 +1389,7 @@ class MoCoPCI(nn.Module):
         xyz = torch.cat([xyz1, xyz2], dim=0).transpose(1, 2).contiguous()
         self._live = {**dict(self.named_parameters()), **dict(self.named_buffers())}
         self._mode = (float(self.drop_rate), float(self.attn_drop_rate), float(self.drop_path_rate)) if self.training else None
+        self._train_lane0 = self.TRAIN_PYRAMID_LANE and not (xyz1.requires_grad or xyz2.requires_grad)
         try:
             with torch.enable_grad(), ops.backend().cloud_scope():
                 self._sched = Schedule(self, xyz.device)
