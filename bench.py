@@ -306,6 +306,36 @@ def quality_on_scan_weights(dev):
             "chamfer_vs_gt": cd, "emd_vs_gt": emd, "chamfer_of_copying_frame_1": ident, "mean_sq_norm_of_gt": e_gt2}
 
 
+def run_train_step(args):
+    """One JSON line: milliseconds per training step on one GPU (SURVEY 8(f) #3; see DESIGN.md section 8)."""
+    from mocopci_amd import synth, training
+    from mocopci_amd.model import MoCoPCI
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    net = MoCoPCI()
+    net.load_state_dict(synth.weights_by_name(net._spec), strict=True)
+    net = net.to(dev)
+    net.train(args.train_step == "train")
+    opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+    x1, x2, gt = synth.make_batch(2, CONFIGS["c2"]["batch"], CONFIGS["c2"]["npoints"], device=dev)
+    gtc = [g.transpose(1, 2).contiguous() for g in gt]
+    losses = []
+    for _ in range(max(1, args.warmup)):
+        losses.append(training.train_step(net, opt, x1, x2, gtc)[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(training.train_step(net, opt, x1, x2, gtc)[0])   # returns the loss as a float: one host sync per step, as train.py has
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    print(json.dumps({"metric": "training step time", "value": ms, "unit": "ms", "higher_is_better": False, "n_gpus": 1, "steps": args.steps,
+                      "warmup": max(1, args.warmup), "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"MoCoPCI training step, N={CONFIGS['c2']['npoints']}, B={CONFIGS['c2']['batch']}, module mode {args.train_step}",
+                                 "objective": "train.py:135-160 multi-scale Chamfer, clip 2.0, Adam"},
+                      "loss_first_last": [losses[0], losses[-1]], "peak_memory_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+                      "vs_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,7 +353,15 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="steps in flight: consecutive steps issued round-robin on this many HIP streams "
                                                             "(measured: 2-3 give 0-10 %% depending on how the runtime maps the ~15 streams onto its 4 "
                                                             "hardware queues, not reproducibly; more hardware queues make it worse)")
+    ap.add_argument("--train-step", choices=("eval", "train"), default=None,
+                    help="NOT the BASELINE metric: time one training step (forward(train=True) + train.py's multi-scale Chamfer objective + "
+                         "backward + clipped Adam, mocopci_amd/training.py) at the configs[1] shape instead; eval = the inference graph "
+                         "differentiated, train = after net.train() (batch-statistics BatchNorm, dropout: the reference's mode, train.py:130)")
     args = ap.parse_args()
+    if args.train_step is not None:
+        if args.gpus != 1:
+            raise SystemExit("--train-step is a single-GPU measurement")
+        return run_train_step(args)
 
     global NPOINTS, B_PER_GPU
     if args.config == "c5":
