@@ -206,7 +206,9 @@ class _AttentionSmallFn(torch.autograd.Function):
 
 class _LinearFn(torch.autograd.Function):
     """The fused Linear (+ one-slope activation, + residual) with an explicit backward: two GEMMs and a mask taken from the saved
-    OUTPUT (for 0 <= slope <= 1 the output of act is positive exactly where its argument is), instead of evaluating the layer again under autograd."""
+    OUTPUT (for 0 <= slope <= 1 the output of act is positive exactly where its argument is), instead of evaluating the layer again
+    under autograd.  With a residual the activation's output is recovered as y - res: where |act(z)| is below the rounding of that
+    difference the mask may differ from sign(z) -- entries on the activation's kink, where either slope is a valid subgradient."""
 
     @staticmethod
     def forward(ctx, fused, x, w, b, slope, res):
