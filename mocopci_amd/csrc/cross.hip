@@ -104,7 +104,7 @@ __device__ __forceinline__ int scatter_reg(int lane) { return ((lane >> 4) & 1) 
 template <int D>
 struct CrossLds {
     static constexpr int T = D / 32;
-    static constexpr bool BF = D != 256;  // D -> D layer on the split-bf16 path
+    static constexpr bool BF = true;      // D -> D layer on the split-bf16 path (D = 256 too: cross256_stream_kernel below)
     // f32 image [t_out][kquad][lane][4] = D*D floats; split image [t_out][kstep = 2T][piece = 3][lane] x uint4 = 1.5 D*D floats
     static constexpr int W_FLOATS = BF ? T * (2 * T) * 3 * 64 * 4 : T * (T * 16 / 4) * 64 * 4;
     static constexpr int POS_FLOATS = T * 2 * 64;               // [t][kstep][lane]
@@ -306,6 +306,131 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
     }
 }
 
+// ---- D = 256 (cross3, pointconv_util.py:783-791) on the split-bf16 path -------------------------------------------------------
+// The three bf16 pieces of the 256 x 256 layer are 393 KB: they do not fit the CU's LDS, and splitting the output channels over
+// workgroups (round 3's form: two halves on the f32-input MFMA, 16/6 of the matrix time; a four-quarter split-bf16 build was no
+// faster) makes every workgroup rebuild x0 -- the gather of 32 KB and ~1 500 vector instructions per point, which is what those
+// forms spend their time on.  Here a point's x0 is built ONCE and stays in registers as the 16 split k-steps (192 VGPRs, one wave per
+// SIMD), and the weights stream past it: the workgroup's four waves (one point each) walk the eight 32-channel output tiles in
+// lockstep, tile t + 1's pieces (49 KB, the same for every point) are fetched from L2 into registers while tile t runs on the MFMA
+// pipe and written to the other half of a double-buffered LDS tile behind it -- one barrier per tile, 393 KB of L2 reads per four
+// points.  Same arithmetic as the D = 64 / 128 kernel (six bf16 MFMAs per 16 k-values, small terms first, bias as the initial
+// accumulator), 768 MFMAs x 32 cycles per point against 1 024 x 64 on the f32-input MFMA.
+constexpr int X256_T = 8, X256_KS = 16, X256_TILE_U4 = X256_KS * 3 * 64, X256_WAVES = 4;
+__global__ __launch_bounds__(64 * X256_WAVES, 1) void cross256_stream_kernel(long long total, int n1, int n2, const float *__restrict__ xyz1,
+                                                                          const float *__restrict__ xyz2, const float *__restrict__ points1,
+                                                                          const float *__restrict__ points2, const int *__restrict__ idx,
+                                                                          const int *__restrict__ idx2, const int *__restrict__ bmap, int shared,
+                                                                          const float *__restrict__ packed, float *__restrict__ out) {
+    using L = CrossLds<256>;
+    constexpr int D = 256, T = X256_T, WAVES = X256_WAVES, SMALL = L::POS_FLOATS + L::B_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4 *wbuf = reinterpret_cast<uint4 *>(lds);                            // [2][X256_TILE_U4]
+    float *small = lds + 2 * X256_TILE_U4 * 4;                               // pos | bias
+    float *row1_all = small + SMALL;                                          // [WAVES][D]
+    int *bmap_lds = reinterpret_cast<int *>(row1_all + WAVES * D);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    const uint4 *wimg = reinterpret_cast<const uint4 *>(packed + L::OFF_W);   // [t_out][k-step][piece][lane]
+    for (int e = tid; e < SMALL / 4; e += 64 * WAVES) reinterpret_cast<float4 *>(small)[e] = reinterpret_cast<const float4 *>(packed + L::OFF_POS)[e];
+    if (bmap) {
+        const int nb = (int)(total / n1);
+        for (int e = tid; e < nb; e += 64 * WAVES) bmap_lds[e] = bmap[e];
+    }
+    for (int e = tid; e < X256_TILE_U4; e += 64 * WAVES) wbuf[e] = wimg[e];   // tile 0
+    __syncthreads();
+    const float *lpos = small, *lbias = small + L::POS_FLOATS;
+    float *row1_lds = row1_all + wave * D;
+    auto mapped = [&](int bb, int flag) -> long long { return (bmap && (shared & flag)) ? (long long)bmap_lds[bb] : (long long)bb; };
+
+    const long long per_round = (long long)gridDim.x * WAVES;
+    const long long first = (long long)blockIdx.x * WAVES;
+    const int rounds = first < total ? (int)((total - first + per_round - 1) / per_round) : 0;  // the same for the four waves of the workgroup
+    // No load pipeline across rounds here: the kernel is bound by the weight stream (402 MB of L2 reads per 4096 points), and a build
+    // that kept the next round's gathered rows in flight (cross_kernel's scheme, 446 VGPRs) measured 125 vs 118 us alone, 174 vs 160 in the step.
+    int cur = 0;
+    for (int g = 0; g < rounds; ++g) {
+        const long long pw = first + (long long)g * per_round + wave;
+        const bool live = pw < total;
+        const long long p = live ? pw : total - 1;  // a wave without a point works on the last one and does not store
+        const int bb = (int)(p / n1), off = (int)(p - (long long)bb * n1);
+        int id;
+        if (!idx2) {
+            id = idx[p * KNB + col];
+        } else {
+            const long long ps = mapped(bb, 4) * n1 + off;
+            id = col >= 16 ? idx2[p * 16 + col - 16] : idx[ps * 16 + col];
+        }
+        const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
+        const float dx = q2[0] - xyz1[p * 3 + 0], dy = q2[1] - xyz1[p * 3 + 1], dz = q2[2] - xyz1[p * 3 + 2];
+        const float in0 = h ? dy : dx, in1 = h ? 1.0f : dz;  // k-step 0: (dx,dy); k-step 1: (dz,1)
+        const float4 *row2 = reinterpret_cast<const float4 *>(points2 + (mapped(bb, 2) * n2 + id) * D);
+        const float4 *row1 = reinterpret_cast<const float4 *>(points1 + (mapped(bb, 1) * n1 + off) * D);
+        reinterpret_cast<float4 *>(row1_lds)[lane] = row1[lane];  // D / 4 = 64 float4: one per lane
+        __builtin_amdgcn_wave_barrier();
+        McpSplit3 xs[2 * T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x16 acc;
+            float4 rg[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 a = reinterpret_cast<const float4 *>(row1_lds)[(32 * t + 8 * gq + 4 * h) >> 2];
+                rg[gq] = row2[(32 * t + 8 * gq + 4 * h) >> 2];
+                acc[4 * gq + 0] = a.x; acc[4 * gq + 1] = a.y; acc[4 * gq + 2] = a.z; acc[4 * gq + 3] = a.w;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lpos[(t * 2 + 0) * 64 + lane], in0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lpos[(t * 2 + 1) * 64 + lane], in1, acc, 0, 0, 0);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                acc[4 * gq + 0] = leaky(acc[4 * gq + 0] + rg[gq].x);
+                acc[4 * gq + 1] = leaky(acc[4 * gq + 1] + rg[gq].y);
+                acc[4 * gq + 2] = leaky(acc[4 * gq + 2] + rg[gq].z);
+                acc[4 * gq + 3] = leaky(acc[4 * gq + 3] + rg[gq].w);
+            }
+            xs[2 * t + 0] = mcp_split_kstep(acc, 0);
+            xs[2 * t + 1] = mcp_split_kstep(acc, 1);
+        }
+        __builtin_amdgcn_wave_barrier();  // the points1 row has been read: the next round may overwrite it
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            // the next tile's pieces (the first tile again after the last: the next round starts with it) on their way while this one runs
+            const bool more = t + 1 < T || g + 1 < rounds;
+            const uint4 *nsrc = wimg + (size_t)((t + 1) & (T - 1)) * X256_TILE_U4 + tid;
+            uint4 nx[X256_TILE_U4 / (64 * X256_WAVES)];
+#pragma unroll
+            for (int i = 0; i < X256_TILE_U4 / (64 * WAVES); ++i) nx[i] = more ? nsrc[i * 64 * WAVES] : make_uint4(0u, 0u, 0u, 0u);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = lbias[(t * 2 + h) * 16 + r];
+            acc = mcp_tile_split<2 * T>(wbuf + (size_t)cur * X256_TILE_U4 + lane, xs, acc);
+            const float m = leaky(scatter_max(acc, lane));  // leaky is monotone: it commutes with the max
+            if (live && (lane & 1) == 0) out[p * D + 32 * t + chan_of(scatter_reg(lane), h)] = m;
+            uint4 *ndst = wbuf + (size_t)(cur ^ 1) * X256_TILE_U4 + tid;
+#pragma unroll
+            for (int i = 0; i < X256_TILE_U4 / (64 * WAVES); ++i) ndst[i * 64 * WAVES] = nx[i];
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+}
+
+int launch_cross256(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2, const int *idx,
+                    const int *idx2, const int *bmap, int shared, const float *packed, float *out, hipStream_t s) {
+    using L = CrossLds<256>;
+    const size_t lds = (size_t)2 * X256_TILE_U4 * 16 + (size_t)(L::POS_FLOATS + L::B_FLOATS + X256_WAVES * 256 + (bmap ? MAX_MAPPED_BATCH : 0)) * sizeof(float);
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cross256_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_once.done();
+    }
+    const long long want = (total + X256_WAVES - 1) / X256_WAVES;
+    const unsigned grid = (unsigned)max(1LL, min(want, 256LL));  // one resident workgroup per CU
+    hipLaunchKernelGGL(cross256_stream_kernel, dim3(grid), dim3(64 * X256_WAVES), lds, s, total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared,
+                       packed, out);
+    return mcp_launch_status();
+}
+
 template <int D, int SPLIT>
 int launch_cross(long long total, int n1, int n2, const float *xyz1, const float *xyz2, const float *points1, const float *points2,
                  const int *idx, const int *idx2, const int *bmap, int shared, const float *packed, float *out, hipStream_t s) {
@@ -358,7 +483,7 @@ MCP_EXPORT int mcp_cross_volume(int b, int n1, int n2, int d, int k, const float
     mcp_prof_begin(MCP_KERNEL_CROSS, s);
     const int rc = d == 64    ? launch_cross<64, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared, packed, out, s)
                    : d == 128 ? launch_cross<128, 1>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared, packed, out, s)
-                              : launch_cross<256, 2>(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared, packed, out, s);
+                              : launch_cross256(total, n1, n2, xyz1, xyz2, points1, points2, idx, idx2, bmap, shared, packed, out, s);
     mcp_prof_end(MCP_KERNEL_CROSS, s);
     return rc;
 }
