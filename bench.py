@@ -61,7 +61,7 @@ NAMES = {
     "knn": "knn_walk (K = 32) / knn_pruned (K <= 16) / knn_queue / knn_small kernels (mcp_knn, mcp_knn_pruned)",
     "knn_cosine": "knn_cosine_kernel (mcp_knn_cosine)",
     "fusion": "fusion_split_kernel (mcp_fusion)",
-    "cross": "cross_kernel<64|128|256> (mcp_cross_volume)",
+    "cross": "cross_kernel<64|128> / cross256_stream_kernel (mcp_cross_volume)",
     "pointconv": "pointconv_linear_kernel / pointconv_agg_kernel (mcp_pointconv_linear, mcp_pointconv_agg)",
     "attention": "attention_small_kernel<8|16> / attention_wide_kernel<32|256> (mcp_attention_small, mcp_attention_wide)",
     "ptblock": "ptblock_kernel (mcp_ptblock_attention)",
@@ -78,7 +78,7 @@ NOTES = {
     "knn_cosine": "2*B*Q*N*C flop on the f32-input MFMA (exact fp32 fma chains: the neighbour indices are compared bit for bit)",
     "fusion": "4->64->64->128 MLP per neighbour, 1.6 MFLOP/point; fp32 products on the bf16 matrix pipe through an exact 3-way operand "
               "split: peak = bf16 dense MFMA peak / 6 partial products per fp32 product",
-    "cross": "B*N1*K*(8C+2C^2) flop; D=64/128 on the split-bf16 path (peak as for fusion), the one D=256 launch per step on the f32-input MFMA",
+    "cross": "B*N1*K*(8C+2C^2) flop; every D on the split-bf16 path (peak as for fusion)",
     "pointconv": "gather + WeightNet + aggregation on the VALU; achieved = gathered rows + aggregate written, B*S*(K*4*(D+3) + 32*(D+3)) bytes "
                  "(the gathers hit L2 / Infinity Cache).  The D = 32 / 64 launches (levels 0, 1, refinement) also run the Linear + LeakyReLU behind "
                  "the aggregation (mcp_pointconv_linear): their aggregate stays in LDS, so they move LESS than this figure and do more",

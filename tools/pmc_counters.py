@@ -28,7 +28,7 @@ FAMILIES = {  # name -> kernel-name substrings
     "build_cloud": ("build_cloud_kernel",),
     "knn_cosine": ("knn_cosine_kernel", "knn_cosine_split_kernel"),
     "fusion": ("fusion_kernel", "fusion_split_kernel"),
-    "cross": ("cross_kernel",),
+    "cross": ("cross_kernel", "cross256_stream_kernel"),
     "pointconv": ("pointconv_agg_kernel", "pointconv_agg_lowlevel_kernel", "pointconv_linear_kernel"),
     "attention": ("attention_small_kernel", "attention_wide_kernel", "attention_kernel"),
     "attention_small": ("attention_small_kernel",),
