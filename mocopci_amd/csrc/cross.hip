@@ -17,12 +17,12 @@
 //     (weights pre-permuted in LDS, as in fusion.hip), bias as the initial accumulator;
 //   * the max over neighbours is a DPP row reduction + one cross-row shuffle per register.
 // HBM/L2 traffic is the compulsory gather (32 rows of D floats per point) + D floats out.
-// D = 256 (cross3, pointconv_util.py:783-791): the 256 KB weight image does not fit the CU's 160 KB of LDS, so the output
-// channels are split over blockIdx.y into two halves of four 32-channel tiles (128 KB of weights resident per workgroup);
-// each half rebuilds x0 from its own gather (an L2-resident 32 KB per point) rather than exchanging it.
-// D = 64 / 128: the D -> D layer runs on the bf16 matrix pipe through the exact three-way operand split of mfma_split.h (six
-// bf16 MFMAs per 16 k-values instead of eight f32-input ones); the weight pieces are prepared once by mcp_cross_pack, x0 is
-// split in registers as layer 1 leaves it.  D = 256 keeps the f32-input MFMA (its split image would need four LDS passes).
+// D = 256 (cross3, pointconv_util.py:783-791): its weight pieces (393 KB) do not fit the CU's 160 KB of LDS; cross256_stream_kernel
+// below builds a point's x0 once, keeps it in registers and streams the pieces past it (rounds 2-3 split the output channels over
+// workgroups on the f32-input MFMA instead, each workgroup rebuilding x0).
+// The D -> D layer runs on the bf16 matrix pipe through the exact three-way operand split of mfma_split.h (six bf16 MFMAs per 16
+// k-values instead of eight f32-input ones) at every D; the weight pieces are prepared once by mcp_cross_pack, x0 is split in
+// registers as layer 1 leaves it.
 #include "common.h"
 #include "mfma_split.h"
 
