@@ -516,3 +516,55 @@ def test_train_mode_dropout_is_drawn_from_the_torch_generator():
     with torch.no_grad():
         e1, e2 = net(x1, x2), net(x1, x2)
     assert all(torch.equal(u, v) for u, v in zip(e1, e2))
+
+
+def test_backward_entry_points_reject_bad_arguments_and_handle_tiny_batches():
+    """The C ABI of the backward kernels: wrong neighbour counts / head dims / feature widths are MCP_ERR_UNSUPPORTED, a short
+    workspace or a null pointer MCP_ERR_BAD_ARG (no launch); and a batch smaller than one workgroup's worth of points (a single
+    cloud of 40 points: 32 of its 40 points are everybody's neighbours) still gives the unfused layer's gradients."""
+    import ctypes
+    from mocopci_amd import _lib, grad
+    lib, be = _lib.load(), ops.backend()
+    f = lambda *s: torch.zeros(*s, device=DEV)
+    i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    p1, idx, w = f(1, 64, 3), i32(1, 64, 64), [f(64, 4), f(64), f(64, 64), f(64), f(128, 64), f(128)]
+    ws = torch.zeros(lib.mcp_fusion_grad_workspace_bytes(1, 64), dtype=torch.uint8, device=DEV)
+    args = lambda nb, wsb: (1, 64, nb, P(p1), P(p1), P(idx), None, *[P(t) for t in w], P(p1), P(f(1, 64, 3)), P(f(1, 64, 64, 3)), P(f(12800)), P(ws), wsb, st)
+    assert lib.mcp_fusion_grad(*args(32, ws.numel())) == 10002          # MCP_ERR_UNSUPPORTED: the layer's k is 32 + 32
+    assert lib.mcp_fusion_grad(*args(64, 16)) == 10001                  # MCP_ERR_BAD_ARG: workspace too small
+    assert lib.mcp_cross_grad_floats(256) == 0 and lib.mcp_cross_grad_floats(64) == 64 * 64 + 5 * 64
+    assert lib.mcp_attention_small_grad_workspace_bytes(2, 100, 8) == 2 * 2 * 8 * 100 * 4
+    q = f(1, 64, 96)
+    assert lib.mcp_attention_small_grad(1, 64, 64, 8, 12, P(q), 96, P(q), 96, P(q), 96, 1.0, 0.0, 0, P(q), P(q), P(q), P(q), P(ws), ws.numel(), st) == 10002
+    assert lib.mcp_attention_small_dropout(1, 64, 64, 8, 8, P(q), 64, P(q), 64, P(q), 64, 1.0, 1.5, 0, P(q), st) == 10001   # drop_p outside [0, 1)
+    torch.cuda.synchronize()
+    # tiny batches through the public operators
+    n = 40
+    a = cloud(220, 1, n).to(DEV)
+    b = a + rnd(221, 1, n, 3, scale=0.2).to(DEV)
+    halves = (be.knn(a, a, 32), be.knn(a, b, 32))
+    wf = [rnd(222 + k, *sh, scale=sc).to(DEV) for k, (sh, sc) in enumerate((((64, 4), 0.5), ((64,), 0.1), ((64, 64), 0.125), ((64,), 0.1), ((128, 64), 0.125), ((128,), 0.1)))]
+    g = rnd(230, 1, n, 3).to(DEV)
+
+    def grads(fn):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (a, b, *wf)]
+        return torch.autograd.grad(fn(*leaves), leaves, g)
+    got = grads(lambda x, y, *ww: be.fusion_mlp(x, y, halves, *ww))
+    want = grads(lambda x, y, *ww: grad.fusion_twin(be.group_rows, x, y, halves, *ww))
+    for u, v in zip(got, want):
+        assert float((u - v).abs().max()) <= 5e-4 * float(v.abs().max()) + 2e-5
+    idx16 = be.knn(a, a, 16)
+    qkv = rnd(231, 1, n, 192).to(DEV)
+    wp = [rnd(232, 64, 3, scale=0.3).to(DEV), rnd(233, 64, scale=0.1).to(DEV)] + [t for k in range(3) for t in (rnd(234 + k, 64, 64, scale=0.125).to(DEV), rnd(238 + k, 64, scale=0.1).to(DEV))]
+    gp = rnd(242, 1, n, 64).to(DEV)
+
+    def pgrads(fn):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (a, qkv, *wp)]
+        x, pq = leaves[0], leaves[1]
+        return torch.autograd.grad(fn(x, pq[..., :64], pq[..., 64:128], pq[..., 128:], leaves[2:]), leaves, gp)
+    got = pgrads(lambda x, q_, k_, v_, ww: be.ptblock_layer(x, q_, k_, v_, idx16, ww))
+    want = pgrads(lambda x, q_, k_, v_, ww: grad.ptblock_twin(be.group_rows, x, q_, k_, v_, idx16, *ww))
+    for u, v in zip(got, want):
+        assert float((u - v).abs().max()) <= 5e-4 * float(v.abs().max()) + 2e-5
