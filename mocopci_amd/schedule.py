@@ -49,6 +49,12 @@ class Schedule:
     current -- waits for that result and is recorded as a user of its memory; provide(node, value, event): a result produced
     elsewhere (the prefetched pyramid)."""
 
+    # Debug mode (tools/schedule_waits.py): a list here makes every node record timing events on its lane (start, done) and every
+    # get() an arrival event on the reading stream, appended as ("run", node, lane, start, done) / ("get", node, reader stream id,
+    # arrival, done): after a synchronize, max(0, arrival -> done) is how long that reader was blocked by that node, in the real
+    # (untraced, pipelined) step.  None (the default) records nothing and creates no timing events.
+    TRACE = None
+
     def __init__(self, model, device):
         self.model, self.device = model, device
         self.items = {}
@@ -76,10 +82,16 @@ class Schedule:
                     aux.wait_event(ev)
         for t in reads:
             t.record_stream(aux)
+        trace = Schedule.TRACE
         with torch.cuda.stream(aux):
+            if trace is not None:
+                start = torch.cuda.Event(enable_timing=True)
+                start.record(aux)
             res = fn()
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=trace is not None)
             ev.record(aux)
+        if trace is not None:
+            trace.append(("run", node, self.model.NODE_LANES.get(node), start, ev))
         self.items[node] = (res, ev)
 
     def provide(self, node, value, event=None):
@@ -99,6 +111,10 @@ class Schedule:
         res, ev = self.items[node]
         if ev is not None:
             cur = torch.cuda.current_stream(self.device)
+            if Schedule.TRACE is not None:
+                arrival = torch.cuda.Event(enable_timing=True)
+                arrival.record(cur)
+                Schedule.TRACE.append(("get", node, cur.stream_id, arrival, ev))
             cur.wait_event(ev)
             for t in _tensors(res):
                 t.record_stream(cur)

@@ -16,6 +16,15 @@ CUDA extension cannot be built; they are replaced by stand-ins BEFORE import:
 
 torch.Tensor.cuda is patched to the identity because mocopci.py:199,205,518,571
 hard-code .cuda().  Nothing here runs on the GPU box (/root/reference is absent there).
+
+Two modes, chosen by the FIRST load() of a process (the reference binds the operator names at import time):
+  * load()                 the six public operator names are rebound to forward-only oracle calls (inference goldens);
+  * load(own_autograd=True) the reference's six autograd.Functions run UNCHANGED -- their forward and their BACKWARD
+                           (pointnet2/pointnet2_utils.py:39-73, :108-153, :156-197) -- on a `pointnet2_cuda` stand-in that exports
+                           the nine *_wrapper entry points of pointnet2/src/pointnet2_api.cpp:10-24 bound to the C oracle (same
+                           argument lists, results written into the caller's tensors), with torch.cuda.FloatTensor / IntTensor
+                           patched to the CPU constructors the Functions allocate through.  Used for the training-gradient
+                           fixture (oracle/make_golden.py train_grad_*): loss.backward() then IS the reference's autograd.
 """
 import importlib
 import os
@@ -31,7 +40,55 @@ def available():
     return os.path.isdir(os.path.join(REF_ROOT, "models"))
 
 
-def _install_standins():
+def _wrapper_module():
+    """`pointnet2_cuda` stand-in with the nine entry points of pointnet2/src/pointnet2_api.cpp:10-24 on the C oracle
+    (sampling.cpp:11-49, group_points.cpp:11-37, ball_query.cpp:16-28, interpolate.cpp:14-56: same integer argument order; outputs
+    and gradient buffers are the caller's tensors, written / accumulated in place as the CUDA kernels do)."""
+    import ctypes
+    from oracle import pointset as orc
+    L, f, i = orc.lib(), orc._f, orc._i
+    m = types.ModuleType("pointnet2_cuda")
+
+    def furthest_point_sampling_wrapper(b, n, m_, points, temp, idx):
+        L.orc_fps(f(points), f(temp), i(idx), b, n, m_)
+        return 1
+
+    def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+        L.orc_gather(f(points), i(idx), f(out), b, c, n, npoints)
+        return 1
+
+    def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+        L.orc_gather_grad(f(grad_out), i(idx), f(grad_points), b, c, n, npoints)
+        return 1
+
+    def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+        L.orc_group(f(points), i(idx), f(out), b, c, n, npoints, nsample)
+        return 1
+
+    def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        L.orc_group_grad(f(grad_out), i(idx), f(grad_points), b, c, n, npoints, nsample)
+        return 1
+
+    def ball_query_wrapper(b, n, m_, radius, nsample, new_xyz, xyz, idx):
+        L.orc_ball_query(f(new_xyz), f(xyz), i(idx), b, n, m_, ctypes.c_float(radius), nsample)
+        return 1
+
+    def three_nn_wrapper(b, n, m_, unknown, known, dist2, idx):
+        L.orc_three_nn(f(unknown), f(known), f(dist2), i(idx), b, n, m_)
+
+    def three_interpolate_wrapper(b, c, m_, n, points, idx, weight, out):
+        L.orc_three_interpolate(f(points), i(idx), f(weight), f(out), b, c, m_, n)
+
+    def three_interpolate_grad_wrapper(b, c, n, m_, grad_out, idx, weight, grad_points):
+        L.orc_three_interpolate_grad(f(grad_out), i(idx), f(weight), f(grad_points), b, c, n, m_)
+
+    for fn in (furthest_point_sampling_wrapper, gather_points_wrapper, gather_points_grad_wrapper, group_points_wrapper,
+               group_points_grad_wrapper, ball_query_wrapper, three_nn_wrapper, three_interpolate_wrapper, three_interpolate_grad_wrapper):
+        setattr(m, fn.__name__, fn)
+    return m
+
+
+def _install_standins(own_autograd=False):
     from oracle import pointset as orc
 
     sys.dont_write_bytecode = True
@@ -85,8 +142,11 @@ def _install_standins():
     p3d.ops, p3d.loss = p3d_ops, p3d_loss
     sys.modules.update({"pytorch3d": p3d, "pytorch3d.ops": p3d_ops, "pytorch3d.loss": p3d_loss})
 
-    sys.modules["pointnet2_cuda"] = types.ModuleType("pointnet2_cuda")
+    sys.modules["pointnet2_cuda"] = _wrapper_module() if own_autograd else types.ModuleType("pointnet2_cuda")
     sys.modules.setdefault("emd_cuda", types.ModuleType("emd_cuda"))
+    if own_autograd:
+        # the Functions allocate through torch.cuda.FloatTensor(B, C, N) / torch.cuda.IntTensor(B, M) (pointnet2_utils.py:25-26, :52, ...)
+        torch.cuda.FloatTensor, torch.cuda.IntTensor = torch.FloatTensor, torch.IntTensor
 
     if not getattr(torch.Tensor, "_mcp_cuda_patched", False):
         torch.Tensor.cuda = lambda self, *a, **k: self
@@ -101,20 +161,28 @@ def _install_standins():
         mod.three_interpolate = lambda f, idx, w: orc.three_interpolate(f, idx, w)
 
     for name in ("pointnet2.pointnet2_utils", "models.pointnet2.pointnet2_utils"):
-        _bind(importlib.import_module(name))
+        mod = importlib.import_module(name)
+        if not own_autograd:
+            _bind(mod)
 
 
 _loaded = {}
 
 
-def load():
-    """Returns a namespace with the reference modules: pointconv_util, pointT_layer2, mocopci."""
+def load(own_autograd=False):
+    """Returns a namespace with the reference modules: pointconv_util, pointT_layer2, mocopci, pointnet2_utils (+ utils, the
+    reference's chamfer_loss, in own_autograd mode)."""
+    if _loaded and _loaded["own_autograd"] != own_autograd:
+        raise RuntimeError("the reference is already imported in the other mode (one mode per process)")
     if not _loaded:
         if not available():
             raise RuntimeError("reference tree not present (this harness only runs in the build container)")
-        _install_standins()
+        _install_standins(own_autograd)
+        _loaded["own_autograd"] = own_autograd
         _loaded["pointconv_util"] = importlib.import_module("models.pointconv_util")
         _loaded["pointT_layer2"] = importlib.import_module("models.pointT_layer2")
         _loaded["mocopci"] = importlib.import_module("models.m_models.mocopci")
         _loaded["pointnet2_utils"] = importlib.import_module("pointnet2.pointnet2_utils")
+        if own_autograd:
+            _loaded["utils"] = importlib.import_module("models.utils")
     return types.SimpleNamespace(**_loaded)

@@ -430,6 +430,17 @@ def test_chamfer_gradients():
 
 
 @pytest.mark.parametrize("module_mode", ["eval", "train"])
+def test_training_gradients_match_the_references_own_autograd_on_gpu(module_mode, capsys):
+    """The HIP path's training iteration (forward(train=True), train.py:135-160's objective, backward through the hand-written
+    backward kernels) against the gradients of the REFERENCE'S OWN autograd (tests/golden/train_grad_b1_n1024.npz: loss parts,
+    per-parameter gradient norms, ~50 whole gradient tensors across encoder / cost volumes / fusion / attention)."""
+    def report(msg):
+        with capsys.disabled():
+            print("\n" + msg)
+    hc.run_train_grad_check(DEV, module_mode, report)
+
+
+@pytest.mark.parametrize("module_mode", ["eval", "train"])
 def test_one_training_step_matches_the_oracle_backend(module_mode):
     """module_mode "train": after net.train() (batch-statistics BatchNorm, dropout rates set to 0 so both runs are deterministic);
     "eval": the inference graph differentiated.

@@ -84,6 +84,17 @@ def test_train_mode_batch_statistics_match_the_reference(oracle_backend, capsys)
     hc.run_train_mode_check("cpu", report)
 
 
+@pytest.mark.parametrize("module_mode", ["eval", "train"])
+def test_training_gradients_match_the_references_own_autograd(oracle_backend, capsys, module_mode):
+    """forward(train=True) + train.py:135-160's objective + backward on the CPU oracle backend against the gradients the
+    REFERENCE computes with its own autograd.Functions (pointnet2/pointnet2_utils.py:39-73, :156-197) -- fixture
+    train_grad_b1_n1024.npz, oracle/make_golden.py."""
+    def report(msg):
+        with capsys.disabled():
+            print("\n" + msg)
+    hc.run_train_grad_check("cpu", module_mode, report)
+
+
 def test_checkpointed_train_mode_blocks_match_the_direct_form(oracle_backend):
     """net.train() forwards recompute their two largest unfused blocks in the backward once they exceed MoCoPCI.CHECKPOINT_BYTES (the
     fusion MLP with batch statistics call by call, dropout attention in chunks of batch elements): with the threshold forced to
