@@ -240,30 +240,35 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_fwd_kernel(long long 
     }
 }
 
-// mean = b + S1 / R, var = S2 / R - (S1 / R)^2 (biased), rstd = 1 / sqrt(var + eps): written into the bn vector; var also to var_out
+// mean = b + S1 / R, var = S2 / R - (S1 / R)^2 (biased), rstd = 1 / sqrt(var + eps): written into the bn vector; var also to var_out.
+// S1, S2 are sums of (z - b) and (z - b)^2 (the conv bias is the shift).  The workgroup partials (fp32, each lane's own short chain)
+// are added HERE in double, in fixed order, and the subtraction is done in double: the error of var is then the fp32 rounding of
+// the partials, ~1e-7 (mean - b)^2 -- a channel whose conv output sits 300 standard deviations away from its bias still gets its
+// variance to 1 %; beyond ~3000 the estimate degrades (torch's two-pass var does not).  (the partial sums used to be
+// added in fp32 as well, which lost another factor of the number of workgroups.)
 __global__ __launch_bounds__(256) void fusion_bn_stats_kernel(const float *__restrict__ partial, int parts, int c, double rows, const float *__restrict__ bias,
                                                              float eps, float *__restrict__ bn_layer, float *__restrict__ var_out) {
     // 16 channels per block, 16 chains per channel (workgroups ch, ch + 16, ... in order), chains added in chain order
-    __shared__ float ca[16][17], cb[16][17];
+    __shared__ double ca[16][17], cb[16][17];
     const int el = threadIdx.x & 15, ch = threadIdx.x >> 4, e = blockIdx.x * 16 + el;
-    float sa = 0.f, sb = 0.f;
+    double sa = 0.0, sb = 0.0;
     if (e < c)
         for (int g = ch; g < parts; g += 16) {
-            sa += partial[(size_t)g * 2 * c + e];
-            sb += partial[(size_t)g * 2 * c + c + e];
+            sa += (double)partial[(size_t)g * 2 * c + e];
+            sb += (double)partial[(size_t)g * 2 * c + c + e];
         }
     ca[ch][el] = sa;
     cb[ch][el] = sb;
     __syncthreads();
     if (ch != 0 || e >= c) return;
-    float a = ca[0][el], b = cb[0][el];
+    double a = ca[0][el], b = cb[0][el];
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
         a += ca[i][el];
         b += cb[i][el];
     }
-    const double m = (double)a / rows;
-    double var = (double)b / rows - m * m;
+    const double m = a / rows;
+    double var = b / rows - m * m;
     if (var < 0.0) var = 0.0;
     bn_layer[e] = (float)((double)bias[e] + m);
     bn_layer[c + e] = (float)(1.0 / sqrt(var + (double)eps));

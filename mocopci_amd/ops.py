@@ -206,25 +206,26 @@ class _AttentionSmallFn(torch.autograd.Function):
 
 class _LinearFn(torch.autograd.Function):
     """The fused Linear (+ one-slope activation, + residual) with an explicit backward: two GEMMs and a mask taken from the saved
-    OUTPUT (for 0 <= slope <= 1 the output of act is positive exactly where its argument is), instead of evaluating the layer again
-    under autograd.  With a residual the activation's output is recovered as y - res: where |act(z)| is below the rounding of that
-    difference the mask may differ from sign(z) -- entries on the activation's kink, where either slope is a valid subgradient."""
+    activation OUTPUT (for 0 <= slope <= 1 the output of act is positive exactly where its argument is), instead of evaluating the
+    layer again under autograd.  With a residual AND an activation the kernel runs without the residual and the sum is made here
+    (the same single rounded addition the kernel's epilogue does, so the same bits): the mask then comes from act(z) itself -- a
+    mask recovered as (y - res) > 0 loses entries with 0 < act(z) < ulp(res) / 2."""
 
     @staticmethod
     def forward(ctx, fused, x, w, b, slope, res):
-        y = fused(x.detach(), w.detach(), None if b is None else b.detach(), slope, None if res is None else res.detach())
+        act_res = res is not None and slope != 1.0
+        y = fused(x.detach(), w.detach(), None if b is None else b.detach(), slope, None if (res is None or act_res) else res.detach())
         ctx.slope, ctx.has_b, ctx.has_res = float(slope), b is not None, res is not None
-        ctx.save_for_backward(x, w, y if slope != 1.0 else None, res if (res is not None and slope != 1.0) else None)
-        return y
+        ctx.save_for_backward(x, w, y if slope != 1.0 else None)
+        return y + res.detach() if act_res else y
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, w, y, res = ctx.saved_tensors
+        x, w, act = ctx.saved_tensors
         n, k = w.shape
         gy = grad_out.reshape(-1, n)
         if ctx.slope != 1.0:
-            act = (y if res is None else y - res).reshape(-1, n)
-            gz = torch.where(act > 0, gy, gy * ctx.slope)
+            gz = torch.where(act.reshape(-1, n) > 0, gy, gy * ctx.slope)
         else:
             gz = gy
         dx = (gz @ w).reshape(x.shape) if ctx.needs_input_grad[1] else None
@@ -554,12 +555,16 @@ class HipBackend:
         if not grad.wants_grad(p1, p2, w1, b1, w2, b2, w3, b3):
             return self._fusion_mlp(p1, p2, idx, w1, b1, w2, b2, w3, b3)
         ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
+        if ia.shape[-1] + (0 if ib is None else ib.shape[-1]) != 64:   # the kernels take the 2 x 32 lists only: autograd over the unfused twin
+            return grad.fusion_twin(self.group_rows, p1, p2, idx, w1, b1, w2, b2, w3, b3)
         return _FusionFn.apply(self, ia.contiguous(), None if ib is None else ib.contiguous(), p1, p2, w1, b1, w2, b2, w3, b3)
 
     def fusion_bn(self, p1, p2, idx, conv, affine, eps):
         """The fusion layer of ONE reference call on batch statistics, differentiable w.r.t. p1, p2, the conv weights and the
         BatchNorm weight / bias: -> (out (B,N,3), bn, var) -- see _FusionBNFn."""
         ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
+        if ia.shape[-1] + (0 if ib is None else ib.shape[-1]) != 64:
+            raise ValueError("fusion_bn: the batch-statistics kernels take 64 neighbours per point (2 x 32 or one list of 64)")
         return _FusionBNFn.apply(self, float(eps), ia.contiguous(), None if ib is None else ib.contiguous(), p1, p2, *conv, *affine)
 
     def fusion_bn_forward(self, p1, p2, idx, conv, affine, eps):
@@ -633,8 +638,9 @@ class HipBackend:
             return self.cross_volume(x1.contiguous(), x2.contiguous(), f1.contiguous(), f2.contiguous(), i, pk, bmap=bmap, shared=shared)
         if bmap is not None:
             return fused(xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp)
-        if grad.wants_grad(xyz1, xyz2, points1, points2, wpos, bpos, wmlp, bmlp) and _lib.load().mcp_cross_grad_floats(wmlp.shape[0]):
-            ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
+        ia, ib = idx if isinstance(idx, (tuple, list)) else (idx, None)
+        k_total = ia.shape[-1] + (0 if ib is None else ib.shape[-1])   # the backward kernel is built for the 32-neighbour lists
+        if grad.wants_grad(xyz1, xyz2, points1, points2, wpos, bpos, wmlp, bmlp) and k_total == 32 and _lib.load().mcp_cross_grad_floats(wmlp.shape[0]):
             return _CrossFn.apply(self, ia.contiguous(), None if ib is None else ib.contiguous(), xyz1, xyz2, points1, points2, wpos, bpos, wmlp, bmlp)
         return grad.run(fused, lambda *a: grad.cross_twin(self.group_rows, *a), xyz1, xyz2, points1, points2, idx, wpos, bpos, wmlp, bmlp)
 

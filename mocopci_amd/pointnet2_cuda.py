@@ -40,22 +40,33 @@ def _segments(idx, n):
 
 # The three backward scatters: the reference's kernels add with atomicAdd (sampling_gpu.cu:46-83, group_points_gpu.cu:8-44,
 # interpolate_gpu.cu:120-161), so their sums depend on the order the hardware serves the atomics in.  These wrappers keep the
-# reference's argument lists and results (grad_points is overwritten with the full sum; the reference adds into the caller's
-# zeros) but reduce each destination's addends in ascending position order: bit-reproducible.
-def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+# reference's argument lists and its CONTRACT -- the scatter is ADDED to what grad_points holds (the reference's callers pass
+# zeros, pointnet2_utils.py:67,146,190; a caller that accumulates into a live buffer gets the same sum here) -- but reduce each
+# destination's addends in ascending position order first, so the result is bit-reproducible.
+# accumulate=False (keyword only, used by this package's own autograd.Functions): grad_points is uninitialised scratch and is
+# overwritten -- no zero fill, no second pass.
+def _scatter(entry, grad_out, grad_points, accumulate, *args):
+    dst = torch.empty_like(grad_points) if accumulate else grad_points
+    rc = _call(entry, grad_out, *args, _lib.fptr(dst))
+    if accumulate:
+        grad_points.add_(dst)
+    return rc
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points, *, accumulate=True):
     order, seg = _segments(idx, n)
-    return _call("mcp_group_points_grad_sorted", grad_out, b, c, n, npoints, _lib.fptr(grad_out), _lib.iptr(order), _lib.iptr(seg),
-                 _lib.fptr(grad_points))
+    return _scatter("mcp_group_points_grad_sorted", grad_out, grad_points, accumulate, b, c, n, npoints, _lib.fptr(grad_out), _lib.iptr(order),
+                    _lib.iptr(seg))
 
 
 def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
     return _call("mcp_group_points", points, b, c, n, npoints, nsample, _lib.fptr(points), _lib.iptr(idx), _lib.fptr(out))
 
 
-def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points, *, accumulate=True):
     order, seg = _segments(idx, n)
-    return _call("mcp_group_points_grad_sorted", grad_out, b, c, n, npoints * nsample, _lib.fptr(grad_out), _lib.iptr(order), _lib.iptr(seg),
-                 _lib.fptr(grad_points))
+    return _scatter("mcp_group_points_grad_sorted", grad_out, grad_points, accumulate, b, c, n, npoints * nsample, _lib.fptr(grad_out),
+                    _lib.iptr(order), _lib.iptr(seg))
 
 
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
@@ -70,7 +81,7 @@ def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     _call("mcp_three_interpolate", points, b, c, m, n, _lib.fptr(points), _lib.iptr(idx), _lib.fptr(weight), _lib.fptr(out))
 
 
-def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points, *, accumulate=True):
     order, seg = _segments(idx, m)
-    _call("mcp_three_interpolate_grad_sorted", grad_out, b, c, n, m, _lib.fptr(grad_out), _lib.iptr(order), _lib.iptr(seg), _lib.fptr(weight),
-          _lib.fptr(grad_points))
+    _scatter("mcp_three_interpolate_grad_sorted", grad_out, grad_points, accumulate, b, c, n, m, _lib.fptr(grad_out), _lib.iptr(order),
+             _lib.iptr(seg), _lib.fptr(weight))

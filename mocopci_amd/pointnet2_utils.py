@@ -59,8 +59,8 @@ class GatherOperation(Function):
     def backward(ctx, grad_out):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.size()
-        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
-        pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
+        grad_features = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
+        pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features, accumulate=False)
         return grad_features, None
 
 
@@ -109,8 +109,8 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
-        grad_features = torch.zeros((B, c, m), dtype=torch.float32, device=grad_out.device)
-        pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
+        grad_features = torch.empty((B, c, m), dtype=torch.float32, device=grad_out.device)
+        pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features, accumulate=False)
         return grad_features, None, None
 
 
@@ -135,8 +135,8 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.size()
-        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
-        pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
+        grad_features = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
+        pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features, accumulate=False)
         return grad_features, None
 
 

@@ -6,14 +6,16 @@ ALPHA = (1.0, 0.8, 0.4, 0.2)  # train.py:138
 
 def chamfer_loss(pred, gt, rows=None):
     """models/utils.py:36-45 on the layouts train.py uses: pred (B,n,3) (the reference permutes its (B,n,3) frame to (B,3,n) and
-    chamfer_loss permutes it back), gt (B,3,n).  rows: a memo {id(gt): its (B,n,3) copy} so that a ground-truth cloud compared with
-    several predictions is laid out once (and, inside a cloud_scope, sorted for the neighbour searches once)."""
+    chamfer_loss permutes it back), gt (B,3,n).  rows: a memo {id(gt): (gt, its (B,n,3) copy)} so that a ground-truth cloud compared
+    with several predictions is laid out once (and, inside a cloud_scope, sorted for the neighbour searches once).  The entry holds
+    gt itself: a temporary view (zip over a stacked tensor) would otherwise die and hand its id to the next frame's view."""
     if rows is None:
         g = gt.transpose(1, 2).contiguous()
     else:
-        g = rows.get(id(gt))
-        if g is None:
-            g = rows[id(gt)] = gt.transpose(1, 2).contiguous()
+        hit = rows.get(id(gt))
+        if hit is None or hit[0] is not gt:
+            hit = rows[id(gt)] = (gt, gt.transpose(1, 2).contiguous())
+        g = hit[1]
     return ops.backend().chamfer(pred.contiguous(), g)
 
 

@@ -272,6 +272,36 @@ def test_fusion_on_batch_statistics_matches_autograd_over_the_unfused_layer_and_
         assert err <= 5e-4 * scale + floor, f"grad {name}: max err {err:.2e}, gradient scale {scale:.2e}"
 
 
+def test_fusion_batch_statistics_of_a_channel_far_from_its_bias():
+    """A layer-2 conv whose outputs sit ~100 standard deviations away from the conv bias (positive weights on inputs that layer 1's
+    BatchNorm pins near 1): the variance comes from S2 / R - (S1 / R)^2 around the bias, so the cancellation eats ~1e-7 * 100^2 of
+    it (with the workgroup partials added in fp32 it was the number of workgroups times more).  Against float64."""
+    be = ops.backend()
+    B, N = 4, 4096
+    p1 = cloud(180, B, N).to(DEV)
+    p2 = p1 + rnd(181, B, N, 3, scale=0.2).to(DEV)
+    halves = (be.knn(p1, p1, 32), be.knn(p1, p2, 32))
+    conv = [t.to(DEV) for t in (rnd(182, 64, 4, scale=0.5), rnd(183, 64, scale=0.3), rnd(184, 64, 64, scale=0.125).abs(), rnd(185, 64, scale=0.3),
+                                rnd(186, 128, 64, scale=0.125), rnd(187, 128, scale=0.3))]
+    aff = [t.to(DEV) for t in (torch.full((64,), 0.06), torch.ones(64), 1 + rnd(170, 64, scale=0.2), rnd(171, 64, scale=0.2),
+                               1 + rnd(172, 128, scale=0.2), rnd(173, 128, scale=0.2))]
+    out, bn, var = be.fusion_bn_forward(p1, p2, halves, conv, aff, 1e-3)
+    whole = torch.cat(halves, dim=-1).long()
+    bi = torch.arange(B, device=DEV).view(B, 1, 1)
+    nb = p2.double()[bi, whole]
+    r = nb - p1.double().unsqueeze(2)
+    x = torch.cat([r, r.norm(dim=-1, keepdim=True)], dim=-1)
+    z1 = (x @ conv[0].double().T + conv[1].double()).reshape(-1, 64)
+    v1 = torch.relu((z1 - z1.mean(0)) * (aff[0].double() * torch.rsqrt(z1.var(0, unbiased=False) + 1e-3)) + aff[1].double())
+    z2 = v1 @ conv[2].double().T + conv[3].double()
+    mean2, var2 = z2.mean(0), z2.var(0, unbiased=False)
+    ratio = ((mean2 - conv[3].double()).abs() / var2.sqrt())
+    assert float(ratio.min()) > 30, float(ratio.min())     # the case is what it claims to be
+    torch.testing.assert_close(bn[256:320].double(), mean2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(var[64:128].double(), var2, rtol=1e-2, atol=0)
+    assert torch.isfinite(out).all()
+
+
 @pytest.mark.parametrize("heads,hd,nq,nk,bf", [(8, 8, 333, 517, 3), (8, 8, 2048, 2048, 2), (4, 16, 200, 64, 2), (8, 16, 130, 1000, 1)])
 def test_attention_small_backward_kernels_match_the_dense_formulation_and_repeat(heads, hd, nq, nk, bf):
     """mcp_attention_small_grad against float64 autograd over softmax(q k^T scale) v: ragged query / key counts (partial tiles on both
@@ -415,11 +445,14 @@ def test_mlp2_gradients(cin, hidden, cout):
                   [x, res, *w, slope], names=["x", "res", "w1", "b1", "w2", "b2", "slope"])
 
 
-def test_linear_gradients():
-    x, res = rnd(96, 20000, 64), rnd(97, 20000, 32)
+@pytest.mark.parametrize("slope,res_scale", [(0.1, 1.0), (0.0, 1e6)])
+def test_linear_gradients(slope, res_scale):
+    """(0.0, 1e6): ReLU with residuals so large that act(z) vanishes in y = act(z) + res for most entries -- the mask must still be
+    the sign of z (the reference's autograd), not of y - res."""
+    x, res = rnd(96, 20000, 64), rnd(97, 20000, 32, scale=res_scale)
     w, b = rnd(98, 32, 64, scale=0.125), rnd(99, 32, scale=0.1)
     ob, be = OracleBackend(), ops.backend()
-    compare_grads(lambda a, r, ww, bb: be.linear(a, ww, bb, 0.1, r), lambda a, r, ww, bb: ob.linear(a, ww, bb, 0.1, r), [x, res, w, b],
+    compare_grads(lambda a, r, ww, bb: be.linear(a, ww, bb, slope, r), lambda a, r, ww, bb: ob.linear(a, ww, bb, slope, r), [x, res, w, b],
                   names=["x", "res", "w", "b"])
 
 

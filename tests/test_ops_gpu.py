@@ -120,6 +120,31 @@ def test_reference_api_backward_scatters_are_deterministic_and_exact():
     assert torch.equal(runs[0].cpu(), orc.three_interpolate_grad(go3, idx3, w3, 64))
 
 
+def test_reference_api_grad_wrappers_add_into_the_callers_buffer():
+    """The reference's backward kernels atomicAdd into grad_points (sampling_gpu.cu:46-83, group_points_gpu.cu:8-44,
+    interpolate_gpu.cu:120-161): a caller that passes a buffer that already holds something gets base + scatter."""
+    from mocopci_amd import pointnet2_cuda as pn2
+    g = torch.Generator().manual_seed(19)
+    B, C, N = 2, 5, 64
+    base = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, 40), generator=g, dtype=torch.int32)
+    go = torch.randn(B, C, 40, generator=g)
+    buf = base.to(DEV)
+    pn2.gather_points_grad_wrapper(B, C, N, 40, go.to(DEV), idx.to(DEV), buf)
+    assert torch.equal(buf.cpu(), base + orc.gather_operation_grad(go, idx, N))
+    gidx = torch.randint(0, N, (B, 40, 8), generator=g, dtype=torch.int32)
+    go = torch.randn(B, C, 40, 8, generator=g)
+    buf = base.to(DEV)
+    pn2.group_points_grad_wrapper(B, C, N, 40, 8, go.to(DEV), gidx.to(DEV), buf)
+    assert torch.equal(buf.cpu(), base + orc.grouping_operation_grad(go, gidx, N))
+    idx3 = torch.randint(0, N, (B, 90, 3), generator=g, dtype=torch.int32)
+    w3 = torch.rand(B, 90, 3, generator=g)
+    go = torch.randn(B, C, 90, generator=g)
+    buf = base.to(DEV)
+    pn2.three_interpolate_grad_wrapper(B, C, 90, N, go.to(DEV), idx3.to(DEV), w3.to(DEV), buf)
+    assert torch.equal(buf.cpu(), base + orc.three_interpolate_grad(go, idx3, w3, N))
+
+
 @pytest.mark.parametrize("radius,nsample", [(0.5, 16), (1.0, 16), (2.0, 8), (4.0, 8), (1e-4, 4)])
 def test_ball_query_bit_exact(radius, nsample):
     xyz = cloud(11, 2, 16384, extent=(50.0, 50.0, 4.0))  # config 4 shape
