@@ -194,12 +194,23 @@ __global__ __launch_bounds__(64 * RS) void knn_cosine_split_kernel(int q, int n,
     const int qi = blockIdx.x * 32 + col;
     const bool live = qi < q;
     const float *qrow = nq + ((size_t)b * q + (live ? qi : 0)) * C;
-    float bq[C / 2];   // channel parity h of the query's row: whole 16-byte loads, two of the four floats kept
+    // channel parity h of the query's row (the B operand of k-step i is channel 2i + h).  C <= 128: in registers (whole 16-byte loads,
+    // two of the four floats kept).  C = 256 would be 128 registers per lane -- with the staging sets and the selection lists that
+    // spilled 74 of them (round 4) -- so there the workgroup's 32 queries sit in LDS once, [k-step][lane], shared by its RS waves:
+    // one conflict-free ds_read_b32 per 64-cycle MFMA.
+    constexpr bool QL = C > 128;
+    float bq[QL ? 1 : C / 2];
+    float *ql = smem + (size_t)RS * QS * 64 * 2;   // behind the queues (uint2 = two floats)
+    if (QL) {
+        for (int i = wave; i < C / 2; i += RS) ql[i * 64 + lane] = qrow[2 * i + h];
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int j = 0; j < C / 4; ++j) {
-        const float4 v = reinterpret_cast<const float4 *>(qrow)[j];
-        bq[2 * j] = h ? v.y : v.x;
-        bq[2 * j + 1] = h ? v.w : v.z;
+        for (int j = 0; j < (QL ? 0 : C / 4); ++j) {
+            const float4 v = reinterpret_cast<const float4 *>(qrow)[j];
+            bq[QL ? 0 : 2 * j] = h ? v.y : v.x;
+            bq[QL ? 0 : 2 * j + 1] = h ? v.w : v.z;
+        }
     }
     nr += (size_t)b * n * C;
 
@@ -228,8 +239,10 @@ __global__ __launch_bounds__(64 * RS) void knn_cosine_split_kernel(int q, int n,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             // channels 4j .. 4j+3 of the chunk = k-steps 2j (channels 4j, 4j+1) and 2j+1 (4j+2, 4j+3); lane half h holds channel parity h
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[j].y : v[j].x, bq[c * 16 + 2 * j], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[j].w : v[j].z, bq[c * 16 + 2 * j + 1], acc, 0, 0, 0);
+            const float q0 = QL ? ql[(c * 16 + 2 * j) * 64 + lane] : bq[QL ? 0 : c * 16 + 2 * j];
+            const float q1 = QL ? ql[(c * 16 + 2 * j + 1) * 64 + lane] : bq[QL ? 0 : c * 16 + 2 * j + 1];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[j].y : v[j].x, q0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[j].w : v[j].z, q1, acc, 0, 0, 0);
         }
     };
     float4 va[8], vb[8];
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(64 * RS) void knn_cosine_split_kernel(int q, int n,
 template <int C, int RS>
 int launch_cosine_split(int b, int q, int n, int k, const float *nq, const float *nr, int *idx, float *dist, hipStream_t s) {
     static_assert(K == QS && (C / 32) % 2 == 0, "the partial lists reuse the queues; chunks are consumed in pairs");
-    const size_t lds = (size_t)RS * QS * 64 * sizeof(uint2);
+    const size_t lds = (size_t)RS * QS * 64 * sizeof(uint2) + (C > 128 ? (size_t)(C / 2) * 64 * sizeof(float) : 0);
     auto kern = knn_cosine_split_kernel<C, RS>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {

@@ -427,8 +427,13 @@ int launch_linear_blocked(long long rows, int n, const Segs &sg, int nseg, int t
 template <int NT>
 int launch_linear(long long rows, int n, const Segs &sg, int nseg, int total_chunks, float slope, const float *packed, const float *res, int rs_,
                   float *out, int os_, hipStream_t s) {
-    if (rows >= 131072 || NT > 4) return launch_linear_nw<NT, 8>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
-    return launch_linear_nw<NT, 4>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+    // NT > 4 (outputs wider than 128 columns in one pass): 4-wave workgroups whatever the row count -- an 8-wave workgroup caps a
+    // wave at 256 registers and NT = 8 then ran with 10 of its accumulators in scratch (round 4's ISA); at 4 waves it has 512.
+    if constexpr (NT > 4) return launch_linear_nw<NT, 4>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+    else {
+        if (rows >= 131072) return launch_linear_nw<NT, 8>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+        return launch_linear_nw<NT, 4>(rows, n, sg, nseg, total_chunks, slope, packed, res, rs_, out, os_, s);
+    }
 }
 
 // Narrow-output Linear with the activation on its INPUT:  out[r, j] = b[j] + sum_k W[j, k] * act(x[r, k]),  j < n <= 4

@@ -280,7 +280,10 @@ __global__ __launch_bounds__(8 * D) __attribute__((amdgpu_waves_per_eu(D == 32 ?
     using C = FusedCfg<D, NT>;
     constexpr int THREADS = C::THREADS, NCH = C::NCH, KP = C::KP, KTOT = C::KTOT, D4 = D / 4, XP = C::XP;
     constexpr int CF = NT * 2 * 3 * 64 * 4;  // floats per chunk of the weight image (chunk_floats(NT) of linear.hip)
-    constexpr int UNR = D == 32 ? 4 : 2;     // neighbour-loop unrolling: D = 64 runs at 128 VGPRs (two 512-thread workgroups per CU), deeper unrolling spills there
+    // neighbour-loop unrolling: D = 64 runs at 128 VGPRs (two 512-thread workgroups per CU).  Unrolled by 2 the compiler keeps 2 registers in
+    // scratch (12 bytes); the spill-free build (unrolled by 1, 118 VGPRs) is SLOWER -- 74.6 vs 66.2 us at encoder level 1, 104.7 vs 93.7 us
+    // at the refinement stage (profiles/r05_pointconv_unroll_ab.txt) -- so the two spilled registers stay; deeper unrolling spills more
+    constexpr int UNR = D == 32 ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) float flds[];
     float(*wl)[K][WN] = reinterpret_cast<float(*)[K][WN]>(flds);                               // [FPPB][K][WN]
     float(*gx)[K][3] = reinterpret_cast<float(*)[K][3]>(flds + FPPB * K * WN);                 // [FPPB][K][3]

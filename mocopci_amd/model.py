@@ -685,6 +685,17 @@ class MoCoPCI(nn.Module):
         packed = None if live else self.derived(("mlp_t_pack", be.name, prefix, tail, bn), lambda: be.mlp2_pack(w1, b1, w2, b2))
         return be.mlp2(x, w1, b1, w2, b2, slope, res=res, packed=packed)
 
+    def pred_head(self, x, prefix):
+        """pred (mocopci.py:790-791 in :1033,:1044): Linear(64 -> 32), ReLU, Linear(32 -> 3) -- inference: ONE launch of the two-layer
+        kernel (ReLU = PReLU with slope 0; the 32-wide hidden activation of 196608 rows never exists); a training forward keeps
+        the two Linears (their explicit backward)."""
+        be = ops.backend()
+        w1, b1, w2, b2 = self.W(prefix + ".0"), self.Bv(prefix + ".0"), self.W(prefix + ".2"), self.Bv(prefix + ".2")
+        if self._live is None and be.mlp2_supported(w1.shape[1], w1.shape[0], w2.shape[0]):
+            packed = self.derived(("pred_pack", be.name, prefix), lambda: be.mlp2_pack(w1, b1, w2, b2))
+            return be.mlp2(x, w1, b1, w2, b2, 0.0, packed=packed)
+        return self.lin(self.lin(x, prefix + ".0", slope=0.0), prefix + ".2")
+
     def multi_frame_att(self, prefix, x, heads=8, rows=None, feats=True):
         """Multi_Frame_Att.forward (mocopci.py:551-575) batched, on the INNER frames only.  The reference runs 5 frames
         and returns frames[:, 1:-1].  Every operator in between is per frame and per point (eval-mode BatchNorm, 1x1
@@ -1231,7 +1242,7 @@ class MoCoPCI(nn.Module):
             shape = self.transformer_block(m + "shape1", dfeat, down)
             upf = ops.backend().interp3(warped, down, shape)
         self._mark("ptblock + interp done")
-        refine = self.lin(self.lin(upf, m + "pred.0", slope=0.0), m + "pred.2")    # (3B,N,3): Linear, ReLU, Linear
+        refine = self.pred_head(upf, m + "pred")                                   # (3B,N,3): Linear, ReLU, Linear
         self._mark("refine coords done")
         final = self.fusion(warped, refine, idx_self=idx_self, calls=3)
         self._mark("fusion done")
