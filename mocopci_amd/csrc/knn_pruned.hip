@@ -52,24 +52,67 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every 
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-// 30-bit Morton code on the per-batch box [lo, hi] (box (B,6): lo xyz, hi xyz)
+__device__ __forceinline__ uint32_t spread2_10(uint32_t v) {  // 10 bits -> every second bit
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+// Which axes the space-filling order runs over (round 5).  The cells are isotropic (one scale for the three axes: per-axis scaling
+// would slice a flat LiDAR cloud into thin slabs with a huge footprint), but an isotropic 3-D code still spends every third bit on the
+// THIN axis at the scale of a tile: an 80 x 80 x 6 scan of 8192 points has tiles of ~300 unit^3, which the Z-curve cuts into two
+// layers of ~10 x 10 x 3 instead of one column of 7 x 7 x 6 -- and a query's neighbourhood (a ball wider than the slab is thick) then
+// meets twice as many tiles.  So: let s = the side of the footprint a PT-point tile would have if the thinnest axis were ignored,
+// sqrt(PT * (product of the other two extents) / n); when the cloud is no thicker than that, the code runs over the other two axes
+// only (10 bits each).  The order only steers the pruning -- any order gives the same neighbours, bit for bit.
+struct CloudCode {
+    int thin;      // axis left out of the code, -1: none (3-D code)
+    float inv;     // cells per unit length
+};
+__device__ __forceinline__ CloudCode cloud_code(const float *bbox, int n, int bits3) {
+    const float e[3] = {bbox[3] - bbox[0], bbox[4] - bbox[1], bbox[5] - bbox[2]};
+    const float ext = fmaxf(fmaxf(e[0], e[1]), e[2]);
+    const int t = e[0] <= e[1] ? (e[0] <= e[2] ? 0 : 2) : (e[1] <= e[2] ? 1 : 2);
+    const float area = e[(t + 1) % 3] * e[(t + 2) % 3];
+    CloudCode c;
+    c.thin = (area > 0.f && e[t] * e[t] * (float)n <= (float)PT * area) ? t : -1;
+    c.inv = ext > 0.f ? (float)(c.thin < 0 ? (1 << bits3) : 1024) / ext : 0.f;
+    return c;
+}
+__device__ __forceinline__ uint32_t cloud_key(const float *p, const float *bbox, const CloudCode cc, int bits3) {
+    uint32_t c[3];
+    const float top = (float)((cc.thin < 0 ? (1 << bits3) : 1024) - 1);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = (uint32_t)fminf(fmaxf((p[a] - bbox[a]) * cc.inv, 0.f), top);
+    if (cc.thin < 0) return spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+    uint32_t u = cc.thin == 0 ? c[1] : c[0], v = cc.thin == 2 ? c[1] : c[2];
+#ifdef MCP_CLOUD_Z2D
+    return spread2_10(u) | (spread2_10(v) << 1);
+#else
+    // two axes: the Hilbert curve's index of cell (u, v) on the 1024 x 1024 grid.  A run of PT consecutive points is then a CONNECTED
+    // piece of the plane (the Z-curve jumps: a run is often two or three separate blocks inside one large box), so the tile boxes
+    // are tighter and a walk meets fewer of them.
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t sft = 10; sft-- > 0;) {
+        const uint32_t rx = (u >> sft) & 1u, ry = (v >> sft) & 1u;
+        d = (d << 2) | ((3u * rx) ^ ry);
+        if (ry == 0) {   // rotate / reflect the quadrant so that the sub-curve enters and leaves where its neighbours expect it
+            if (rx) { u = 1023u - u; v = 1023u - v; }
+            const uint32_t t = u; u = v; v = t;
+        }
+    }
+    return d;
+#endif
+}
+// Morton code (30 bits over three axes, or 20 over two: cloud_code) on the per-batch box [lo, hi] (box (B,6): lo xyz, hi xyz)
 __global__ __launch_bounds__(256) void morton_kernel(int n, const float *__restrict__ xyz, const float *__restrict__ box,
                                                      int *__restrict__ codes) {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float *bx = box + b * 6;
-    const float *p = xyz + ((size_t)b * n + i) * 3;
-    // isotropic cells (one scale for the three axes): LiDAR clouds are flat, per-axis scaling would slice them
-    // into thin slabs with huge x/y extent
-    const float ext = fmaxf(fmaxf(bx[3] - bx[0], bx[4] - bx[1]), bx[5] - bx[2]);
-    uint32_t c[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float t = ext > 0.f ? (p[a] - bx[a]) / ext : 0.f;
-        t = fminf(fmaxf(t * 1024.f, 0.f), 1023.f);
-        c[a] = (uint32_t)t;
-    }
-    codes[(size_t)b * n + i] = (int)(spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2));
+    codes[(size_t)b * n + i] = (int)cloud_key(xyz + ((size_t)b * n + i) * 3, bx, cloud_code(bx, n, 10), 10);
 }
 // one wave per tile of PT sorted points: (lo xyz, hi xyz)
 __global__ __launch_bounds__(64) void tile_box_kernel(int n, int tiles, const float *__restrict__ sorted_xyz, float *__restrict__ boxes) {
@@ -149,31 +192,22 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int tiles, const
         bbox[tid] = v;
     }
     __syncthreads();
-    const float ext = fmaxf(fmaxf(bbox[3] - bbox[0], bbox[4] - bbox[1]), bbox[5] - bbox[2]);
-    // 2. keys: isotropic 10-bit cells (LiDAR clouds are flat: per-axis scaling would slice them into thin slabs);
-    //    thread t holds points t*IPT .. t*IPT+IPT-1, padding sorts last (bit 30)
+    // 2. keys: isotropic cells over three axes or, for a cloud flatter than a tile is wide, over two (cloud_code);
+    //    thread t holds points t*IPT .. t*IPT+IPT-1, padding sorts last (the bit above the codes)
+    const CloudCode cc = cloud_code(bbox, n, CELL_BITS);
     uint32_t keys[IPT], vals[IPT];
 #pragma unroll
     for (int u = 0; u < IPT; ++u) {
         const int i = tid * IPT + u;
-        // CELL_BITS per axis: the order only steers the pruning (any order gives the same neighbours), and a <= 16384-point cloud
-        // has no use for 2^30 cells -- 7 bits per axis (cells of 1/128 of the extent) sort in 6 radix passes instead of 8
-        uint32_t k = 1u << (3 * CELL_BITS);
-        if (i < n) {
-            uint32_t c[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float t = ext > 0.f ? (xyz[(size_t)i * 3 + a] - bbox[a]) / ext : 0.f;
-                t = fminf(fmaxf(t * (float)(1 << CELL_BITS), 0.f), (float)((1 << CELL_BITS) - 1));
-                c[a] = (uint32_t)t;
-            }
-            k = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
-        }
-        keys[u] = k;
+        // CELL_BITS per axis in 3-D: the order only steers the pruning (any order gives the same neighbours), and a <= 16384-point cloud
+        // has no use for 2^30 cells -- 7 bits per axis (cells of 1/128 of the extent) sort in 6 radix passes instead of 8; the 2-D
+        // code has 10 + 10 bits, so both fit below bit 21
+        keys[u] = i < n ? cloud_key(xyz + (size_t)i * 3, bbox, cc, CELL_BITS) : 1u << 21;
         vals[u] = (uint32_t)i;
     }
     // 3. stable radix sort of the (code, index) pairs over the code's bits (padding: the bit above them)
-    typename CloudSort<IPT>::Sort().sort(keys, vals, lds.sort, 0, 3 * CELL_BITS + 1);
+    static_assert(3 * CELL_BITS <= 21, "codes stay below the padding bit");
+    typename CloudSort<IPT>::Sort().sort(keys, vals, lds.sort, 0, 22);
     __syncthreads();
     // 4. permutation + sorted coordinates (sorted position s = tid*IPT + u)
 #pragma unroll
