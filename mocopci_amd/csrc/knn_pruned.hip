@@ -70,19 +70,20 @@ struct CloudCode {
     int thin;      // axis left out of the code, -1: none (3-D code)
     float inv;     // cells per unit length
 };
-__device__ __forceinline__ CloudCode cloud_code(const float *bbox, int n, int bits3) {
+__device__ __forceinline__ CloudCode cloud_code(const float *bbox, int n, int bits3, int bits2) {
     const float e[3] = {bbox[3] - bbox[0], bbox[4] - bbox[1], bbox[5] - bbox[2]};
     const float ext = fmaxf(fmaxf(e[0], e[1]), e[2]);
     const int t = e[0] <= e[1] ? (e[0] <= e[2] ? 0 : 2) : (e[1] <= e[2] ? 1 : 2);
     const float area = e[(t + 1) % 3] * e[(t + 2) % 3];
     CloudCode c;
     c.thin = (area > 0.f && e[t] * e[t] * (float)n <= (float)PT * area) ? t : -1;
-    c.inv = ext > 0.f ? (float)(c.thin < 0 ? (1 << bits3) : 1024) / ext : 0.f;
+    c.inv = ext > 0.f ? (float)(1 << (c.thin < 0 ? bits3 : bits2)) / ext : 0.f;
     return c;
 }
+template <int BITS2>
 __device__ __forceinline__ uint32_t cloud_key(const float *p, const float *bbox, const CloudCode cc, int bits3) {
     uint32_t c[3];
-    const float top = (float)((cc.thin < 0 ? (1 << bits3) : 1024) - 1);
+    const float top = (float)((1 << (cc.thin < 0 ? bits3 : BITS2)) - 1);
 #pragma unroll
     for (int a = 0; a < 3; ++a) c[a] = (uint32_t)fminf(fmaxf((p[a] - bbox[a]) * cc.inv, 0.f), top);
     if (cc.thin < 0) return spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
@@ -90,16 +91,17 @@ __device__ __forceinline__ uint32_t cloud_key(const float *p, const float *bbox,
 #ifdef MCP_CLOUD_Z2D
     return spread2_10(u) | (spread2_10(v) << 1);
 #else
-    // two axes: the Hilbert curve's index of cell (u, v) on the 1024 x 1024 grid.  A run of PT consecutive points is then a CONNECTED
-    // piece of the plane (the Z-curve jumps: a run is often two or three separate blocks inside one large box), so the tile boxes
-    // are tighter and a walk meets fewer of them.
+    // two axes: the Hilbert curve's index of cell (u, v) on the 2^BITS2 x 2^BITS2 grid.  A run of PT consecutive points is then a
+    // CONNECTED piece of the plane (the Z-curve jumps: a run is often two or three separate blocks inside one large box), so the
+    // tile boxes are tighter and a walk meets fewer of them.
     uint32_t d = 0;
+    constexpr uint32_t TOP = (1u << BITS2) - 1u;
 #pragma unroll
-    for (uint32_t sft = 10; sft-- > 0;) {
+    for (uint32_t sft = BITS2; sft-- > 0;) {
         const uint32_t rx = (u >> sft) & 1u, ry = (v >> sft) & 1u;
         d = (d << 2) | ((3u * rx) ^ ry);
         if (ry == 0) {   // rotate / reflect the quadrant so that the sub-curve enters and leaves where its neighbours expect it
-            if (rx) { u = 1023u - u; v = 1023u - v; }
+            if (rx) { u = TOP - u; v = TOP - v; }
             const uint32_t t = u; u = v; v = t;
         }
     }
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void morton_kernel(int n, const float *__restr
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float *bx = box + b * 6;
-    codes[(size_t)b * n + i] = (int)cloud_key(xyz + ((size_t)b * n + i) * 3, bx, cloud_code(bx, n, 10), 10);
+    codes[(size_t)b * n + i] = (int)cloud_key<10>(xyz + ((size_t)b * n + i) * 3, bx, cloud_code(bx, n, 10, 10), 10);
 }
 // one wave per tile of PT sorted points: (lo xyz, hi xyz)
 __global__ __launch_bounds__(64) void tile_box_kernel(int n, int tiles, const float *__restrict__ sorted_xyz, float *__restrict__ boxes) {
@@ -142,16 +144,19 @@ __global__ __launch_bounds__(64) void tile_box_kernel(int n, int tiles, const fl
 // held in registers (IPT per thread): stable, so points of one cell stay in index order -- the same permutation as
 // sorting (code << 32 | index).
 constexpr int BT = 1024;
+// Code width of the fused builder: 15 bits either way -- 5 per axis over three axes (32768 cells) or 7 + 7 over two (16384 cells, Hilbert
+// order) -- so that with the padding bit above them the keys sort in TWO 8-bit radix passes (rocPRIM's match ranking; round 4's 21-bit
+// codes took three).  The order only steers the pruning: <= 16384 points have no use for finer cells than a tile is wide.
 #ifndef MCP_CLOUD_CELL_BITS
-#define MCP_CLOUD_CELL_BITS 7
+#define MCP_CLOUD_CELL_BITS 5
 #endif
-constexpr int CELL_BITS = MCP_CLOUD_CELL_BITS;
+constexpr int CELL_BITS = MCP_CLOUD_CELL_BITS, CELL_BITS_2D = 7, CODE_BITS = 15;
+static_assert(3 * CELL_BITS <= CODE_BITS && 2 * CELL_BITS_2D <= CODE_BITS, "codes stay below the padding bit");
 template <int IPT>
 struct CloudSort {
     using Sort = rocprim::block_radix_sort<uint32_t, BT, IPT, uint32_t>;
     union Lds {
         typename Sort::storage_type sort;
-        uint32_t order[BT * IPT];  // sorted original indices, for the tile boxes
     };
 };
 
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int tiles, const
                                                          float *__restrict__ sorted_xyz, int *__restrict__ perm,
                                                          float *__restrict__ boxes) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dyn[];
-    // dynamic LDS: [0,512) reduction scratch + bbox, then the sort storage / index list
+    // dynamic LDS: [0,512) reduction scratch + bbox, then the sort storage
     float(*red)[BT / 64] = reinterpret_cast<float(*)[BT / 64]>(dyn);     // [6][16] floats = 384 B
     float *bbox = reinterpret_cast<float *>(dyn) + 6 * (BT / 64);          // [6]
     typename CloudSort<IPT>::Lds &lds = *reinterpret_cast<typename CloudSort<IPT>::Lds *>(dyn + 64);
@@ -169,15 +174,16 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int tiles, const
     sorted_xyz += (size_t)b * n * 3;
     perm += (size_t)b * n;
     boxes += (size_t)b * tiles * 6;
-    // 1. bounding box of the cloud
+    // 1. bounding box of the cloud; thread t holds points t*IPT .. t*IPT+IPT-1 (kept in registers for the keys)
+    float px[IPT], py[IPT], pz[IPT];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < n; i += BT) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = xyz[(size_t)i * 3 + a];
-            lo[a] = fminf(lo[a], v);
-            hi[a] = fmaxf(hi[a], v);
-        }
+    for (int u = 0; u < IPT; ++u) {
+        const int i = min(tid * IPT + u, n - 1);   // padding repeats the last point: no effect on the box
+        px[u] = xyz[(size_t)i * 3 + 0]; py[u] = xyz[(size_t)i * 3 + 1]; pz[u] = xyz[(size_t)i * 3 + 2];
+        lo[0] = fminf(lo[0], px[u]); hi[0] = fmaxf(hi[0], px[u]);
+        lo[1] = fminf(lo[1], py[u]); hi[1] = fmaxf(hi[1], py[u]);
+        lo[2] = fminf(lo[2], pz[u]); hi[2] = fmaxf(hi[2], pz[u]);
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -192,58 +198,51 @@ __global__ __launch_bounds__(BT) void build_cloud_kernel(int n, int tiles, const
         bbox[tid] = v;
     }
     __syncthreads();
-    // 2. keys: isotropic cells over three axes or, for a cloud flatter than a tile is wide, over two (cloud_code);
-    //    thread t holds points t*IPT .. t*IPT+IPT-1, padding sorts last (the bit above the codes)
-    const CloudCode cc = cloud_code(bbox, n, CELL_BITS);
+    // 2. keys: isotropic cells over three axes or, for a cloud flatter than a tile is wide, over two (cloud_code); padding sorts
+    //    last (the bit above the codes)
+    const CloudCode cc = cloud_code(bbox, n, CELL_BITS, CELL_BITS_2D);
     uint32_t keys[IPT], vals[IPT];
 #pragma unroll
     for (int u = 0; u < IPT; ++u) {
         const int i = tid * IPT + u;
-        // CELL_BITS per axis in 3-D: the order only steers the pruning (any order gives the same neighbours), and a <= 16384-point cloud
-        // has no use for 2^30 cells -- 7 bits per axis (cells of 1/128 of the extent) sort in 6 radix passes instead of 8; the 2-D
-        // code has 10 + 10 bits, so both fit below bit 21
-        keys[u] = i < n ? cloud_key(xyz + (size_t)i * 3, bbox, cc, CELL_BITS) : 1u << 21;
+        const float p[3] = {px[u], py[u], pz[u]};
+        keys[u] = i < n ? cloud_key<CELL_BITS_2D>(p, bbox, cc, CELL_BITS) : 1u << CODE_BITS;
         vals[u] = (uint32_t)i;
     }
-    // 3. stable radix sort of the (code, index) pairs over the code's bits (padding: the bit above them)
-    static_assert(3 * CELL_BITS <= 21, "codes stay below the padding bit");
-    typename CloudSort<IPT>::Sort().sort(keys, vals, lds.sort, 0, 22);
-    __syncthreads();
-    // 4. permutation + sorted coordinates (sorted position s = tid*IPT + u)
+    // 3. stable radix sort of the (code, index) pairs over the code's bits and the padding bit: points of one cell stay in index order
+    typename CloudSort<IPT>::Sort().sort(keys, vals, lds.sort, 0, CODE_BITS + 1);
+    // 4. permutation + sorted coordinates (sorted position s = tid*IPT + u), and the tile boxes from the same registers: a tile of PT
+    //    sorted points is held by PT / IPT consecutive threads
+    float tl[3] = {INFINITY, INFINITY, INFINITY}, th[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int u = 0; u < IPT; ++u) {
         const int s = tid * IPT + u;
-        lds.order[s] = vals[u];
         if (s < n) {
             const int src = (int)vals[u];
+            const float x = xyz[(size_t)src * 3 + 0], y = xyz[(size_t)src * 3 + 1], z = xyz[(size_t)src * 3 + 2];
             perm[s] = src;
-            sorted_xyz[(size_t)s * 3 + 0] = xyz[(size_t)src * 3 + 0];
-            sorted_xyz[(size_t)s * 3 + 1] = xyz[(size_t)src * 3 + 1];
-            sorted_xyz[(size_t)s * 3 + 2] = xyz[(size_t)src * 3 + 2];
+            sorted_xyz[(size_t)s * 3 + 0] = x;
+            sorted_xyz[(size_t)s * 3 + 1] = y;
+            sorted_xyz[(size_t)s * 3 + 2] = z;
+            tl[0] = fminf(tl[0], x); th[0] = fmaxf(th[0], x);
+            tl[1] = fminf(tl[1], y); th[1] = fmaxf(th[1], y);
+            tl[2] = fminf(tl[2], z); th[2] = fmaxf(th[2], z);
         }
     }
-    __syncthreads();
-    // 5. one box per tile of PT sorted points (a wave per tile)
-    for (int t = wave; t < tiles; t += BT / 64) {
-        float tl[3] = {INFINITY, INFINITY, INFINITY}, th[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int i = t * PT + lane; i < min(n, (t + 1) * PT); i += 64) {
-            const int src = (int)lds.order[i];
+    constexpr int TPT = PT / IPT;   // threads per tile: 8 (IPT = 8) .. 64 (IPT = 1); IPT = 16 (PT / IPT = 4) likewise
+    static_assert(PT % IPT == 0 && TPT >= 1 && TPT <= 64 && (TPT & (TPT - 1)) == 0, "a tile is held by a power-of-two run of lanes");
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float v = xyz[(size_t)src * 3 + a];
-                tl[a] = fminf(tl[a], v);
-                th[a] = fmaxf(th[a], v);
-            }
-        }
+    for (int o = TPT / 2; o > 0; o >>= 1) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            tl[a] = wave_minf(tl[a]);
-            th[a] = wave_maxf(th[a]);
+            tl[a] = fminf(tl[a], __shfl_xor(tl[a], o));
+            th[a] = fmaxf(th[a], __shfl_xor(th[a], o));
         }
-        if (lane == 0) {
-            float *o = boxes + (size_t)t * 6;
-            o[0] = tl[0]; o[1] = tl[1]; o[2] = tl[2]; o[3] = th[0]; o[4] = th[1]; o[5] = th[2];
-        }
+    }
+    const int t = tid / TPT;
+    if ((tid & (TPT - 1)) == 0 && t < tiles) {
+        float *o = boxes + (size_t)t * 6;
+        o[0] = tl[0]; o[1] = tl[1]; o[2] = tl[2]; o[3] = th[0]; o[4] = th[1]; o[5] = th[2];
     }
 }
 
