@@ -53,8 +53,8 @@ CONFIGS = {
 }
 FAMILIES = ("fps", "knn", "knn_cosine", "fusion", "cross", "pointconv", "attention", "ptblock", "mlp", "linear")
 HEADLINE = "fusion"  # the single kernel symbol with the most time on a step's critical (main) stream
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
-PMC_STAMP = os.path.join(ROOT, "profiles", "r04_pmc_sources.json")  # sha256 of every csrc file the profiled library was built from
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")   # tools/profile_round.sh output of this round (counters per launch)
+PMC_STAMP = os.path.join(ROOT, "profiles", "r05_pmc_sources.json")  # sha256 of every csrc file the profiled library was built from
 
 NAMES = {
     "fps": "fps_spatial_kernel / fps_resident_kernel (mcp_furthest_point_sampling_ws)",
@@ -247,7 +247,7 @@ def roofline_entries(timed, calls, steps, pmc):
         p = pmc.get(kname, {})
         if "hbm_bytes_per_launch" in p:
             e["traffic"] = p["hbm_bytes_per_launch"]
-            e["traffic_source"] = "profiles/r04_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build, read side doubled per the gfx950 rule)"
+            e["traffic_source"] = "profiles/r05_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build, read side doubled per the gfx950 rule)"
             e["traffic_stale"] = PMC_IS_STALE
         for key in ("valu_busy_frac_of_chip", "mfma_busy_frac_of_chip", "mean_resident_waves_per_simd"):
             if key in p:
