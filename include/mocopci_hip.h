@@ -189,6 +189,15 @@ int mcp_group_rows_grad(int b, int n, int c, int t, const float *grad_out, const
 int mcp_group_rows_grad_sorted(int b, int n, int c, int t, const float *grad_out, const int *order, const int *seg,
                                float *grad_points, mcp_stream_t stream);
 
+/* The operands of the *_grad_sorted entry points from a gather list: idx (B,T) int32 with values in [0,n) -> order (B,T) = the gather
+ * positions 0..T-1 of each batch element sorted by (destination, position) -- a stable sort's result, whatever order the kernel's
+ * atomics are served in -- and seg (B,n+1) = the CSR offsets.  A counting sort (count / scan / fill / per-row rank: five launches)
+ * in place of a general key-value sort; positions whose value is outside [0,n) are left out (seg[b][n] = the number kept).
+ * workspace: mcp_scatter_segments_workspace_bytes(b,t,n) caller-owned bytes. */
+size_t mcp_scatter_segments_workspace_bytes(int b, int t, int n);
+int mcp_scatter_segments(int b, int t, int n, const int *idx, int *order, int *seg, void *workspace, size_t workspace_bytes,
+                         mcp_stream_t stream);
+
 /* UpsampleFlow.forward (mocopci.py:1485-1502) / the interpolation half of PointWarping (:1472-1479):
  * dense (B,N,3), sparse (B,S,3), feat (B,S,C) channel-last -> out (B,N,C);
  * 3-NN in expansion form, weights 1/max(||d||,1e-10) normalised.  idx3 (int32) and w3 (B,N,3) are
@@ -417,6 +426,16 @@ int mcp_linear(long long rows, int n, int nseg, const float *const *x, const int
  * row another code path computes (mocopci_amd/model.py: speculative / deferred forms of one forward) -- gets the same bits. */
 int mcp_linear_as(long long rows, long long policy_rows, int n, int nseg, const float *const *x, const int *x_stride, const int *k_seg,
                   float slope, const float *packed, const float *res, int res_stride, float *out, int out_stride, mcp_stream_t stream);
+
+/* Weight and bias gradient of a tall Linear y = act(x W^T + b) (autograd over mocopci.py:1111-1127 and the per-point Linears of the
+ * caller graph under train.py:162): dw (n,k) = gz^T x, db (n) = column sums of gz, for gz (rows,n) = gy * act'(z) formed by the
+ * caller and x (rows,k), both row-major with the given row strides (floats).  The rows are
+ * the contraction axis of f32-input MFMAs; workgroup partials are added in workgroup order (bit-reproducible; the number of
+ * workgroups depends on `rows` alone).  n <= 256 and ceil(n/32) ceil(k/32) <= 64 (widths that are not multiples of 32, odd strides:
+ * read element by element, zero-padded); otherwise MCP_ERR_UNSUPPORTED / a workspace size of 0.  db may be NULL.  workspace: mcp_linear_wgrad_workspace_bytes(rows, n, k) caller-owned bytes. */
+size_t mcp_linear_wgrad_workspace_bytes(long long rows, int n, int k);
+int mcp_linear_wgrad(long long rows, int n, int k, const float *gz, int gz_stride, const float *x, int x_stride, float *dw, float *db,
+                     void *workspace, size_t workspace_bytes, mcp_stream_t stream);
 
 /* Fused two-layer per-point MLP (Mlp_T of Multi_Frame_Att, mocopci.py:1558-1565 inside :551-575, and the flow heads
  * trans_block / trans_block_2 -> mapping_xyz, :566-567 / :510-511):

@@ -87,6 +87,10 @@ SIGNATURES = {
     "mcp_mfa_prepare": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "mcp_linear": [ctypes.c_longlong, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _p],
     "mcp_linear_as": [ctypes.c_longlong, ctypes.c_longlong, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _p],
+    "mcp_scatter_segments_workspace_bytes": [_i, _i, _i],
+    "mcp_scatter_segments": [_i, _i, _i, _p, _p, _p, _p, ctypes.c_size_t, _p],
+    "mcp_linear_wgrad_workspace_bytes": [ctypes.c_longlong, _i, _i],
+    "mcp_linear_wgrad": [ctypes.c_longlong, _i, _i, _p, _i, _p, _i, _p, _p, _p, ctypes.c_size_t, _p],
     "mcp_linear_narrow": [ctypes.c_longlong, _i, _i, _p, _i, _p, _p, _f, _p, _i, _p],
     "mcp_mlp2_packed_floats": [_i, _i, _i],
     "mcp_mlp2_pack": [_i, _i, _i, _p, _p, _p, _p, _p, _p],
@@ -98,7 +102,8 @@ SIGNATURES = {
 _RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": ctypes.c_size_t, "mcp_fusion_grad_workspace_bytes": ctypes.c_size_t,
              "mcp_cross_grad_workspace_bytes": ctypes.c_size_t, "mcp_pointconv_agg_grad_workspace_bytes": ctypes.c_size_t,
              "mcp_fusion_bn_workspace_bytes": ctypes.c_size_t, "mcp_fusion_bn_grad_workspace_bytes": ctypes.c_size_t,
-             "mcp_ptblock_grad_workspace_bytes": ctypes.c_size_t, "mcp_attention_small_grad_workspace_bytes": ctypes.c_size_t}
+             "mcp_ptblock_grad_workspace_bytes": ctypes.c_size_t, "mcp_attention_small_grad_workspace_bytes": ctypes.c_size_t,
+             "mcp_linear_wgrad_workspace_bytes": ctypes.c_size_t, "mcp_scatter_segments_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

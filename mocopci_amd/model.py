@@ -206,6 +206,9 @@ class MoCoPCI(nn.Module):
             return be.linear(list(x) if pieces else x, w, b, slope, res, packed=packed, **like)
         if pieces:
             x = torch.cat(list(x), dim=-1)
+        if self._live is not None and x.is_cuda and torch.is_grad_enabled() and x.numel() // x.shape[-1] >= 16384 and 0.0 <= slope <= 1.0:
+            y = ops.plain_linear(x, w, b, slope)   # training, tall input: the library's forward with the streaming backward kernels
+            return y if res is None else y + res
         y = F.linear(x, w, b)
         if slope != 1.0:
             y = F.leaky_relu(y, slope)
@@ -427,7 +430,7 @@ class MoCoPCI(nn.Module):
             sched.run(("swap_f", lvl), lambda: swap(f))   # the "other frame" arrangement the decoder reads
             sched.run(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:], stacked=f)))
             def cos():  # both directions of the feature-space search: the backward one is the forward one with its halves swapped
-                i12 = ops.backend().knn_cosine(f, swap(f), 16)
+                i12 = ops.backend().knn_cosine(f, sched.get(("swap_f", lvl)), 16)   # the swapped copy made by the node above (same lane in the shipped table: no wait)
                 return i12, swap(i12)
             sched.run(("cos", lvl), cos)
 

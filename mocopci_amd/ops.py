@@ -76,13 +76,24 @@ class _GroupRowsFn(torch.autograd.Function):
 
 def _scatter_segments(idx, n):
     """(order, seg) of a gather list (B,...) into rows 0..n-1: the gather positions sorted by destination row (stable) and the row
-    boundaries in that order -- the operands of mcp_group_rows_grad_sorted; one pair serves every tensor gathered with the list."""
+    boundaries in that order -- the operands of mcp_group_rows_grad_sorted; one pair serves every tensor gathered with the list.
+    mcp_scatter_segments: a counting sort on the small keys (csrc/scatter_csr.hip) instead of a general stable key-value sort."""
     B = idx.shape[0]
     T = idx[0].numel()
-    keys, order = torch.sort(idx.reshape(B, T), dim=1, stable=True)
-    bounds = torch.arange(n + 1, device=idx.device, dtype=keys.dtype).expand(B, n + 1).contiguous()
-    seg = torch.searchsorted(keys.contiguous(), bounds).int()
-    return order.int().contiguous(), seg.contiguous()
+    flat = idx.reshape(B, T)
+    if flat.dtype != torch.int32:
+        flat = flat.int()
+    flat = flat.contiguous()
+    order = torch.empty((B, T), dtype=torch.int32, device=idx.device)
+    seg = torch.empty((B, n + 1), dtype=torch.int32, device=idx.device)
+    need = _lib.load().mcp_scatter_segments_workspace_bytes(B, T, n)
+    if need == 0:   # more destinations than the kernel's LDS histograms hold: a general stable sort
+        keys, order64 = torch.sort(flat, dim=1, stable=True)
+        bounds = torch.arange(n + 1, device=idx.device, dtype=keys.dtype).expand(B, n + 1).contiguous()
+        return order64.int().contiguous(), torch.searchsorted(keys.contiguous(), bounds).int().contiguous()
+    ws = torch.empty((need,), dtype=torch.uint8, device=idx.device)
+    _call("mcp_scatter_segments", flat, B, T, n, _lib.iptr(flat), _lib.iptr(order), _lib.iptr(seg), ws.data_ptr(), need)
+    return order, seg
 
 
 def _group_rows_grad(grad_out, idx, n, segments=None):
@@ -204,6 +215,81 @@ class _AttentionSmallFn(torch.autograd.Function):
         return None, dq, dkv, None, None, None, None
 
 
+def _tall_matmul(a, w):
+    """a (rows, n) @ w (n, k) for rows >> n, k (the input gradient of a per-point Linear): the streaming forward kernel on w^T where it
+    is built for the shape (the library GEMM takes ~160 us for 196608 x 64 @ 64 x 32 against ~30), the library otherwise."""
+    be = backend()
+    n, k = w.shape
+    if a.is_cuda and hasattr(be, "linear_kernel_ok") and a.shape[0] >= 8192:
+        a = a.contiguous()
+        if be.linear_kernel_ok(a, k):
+            return be.linear(a, w.t().contiguous(), None, 1.0, None)
+    return a @ w
+
+
+def _wgrad(gz, x):
+    """(gz^T x, column sums of gz) for gz (rows, n), x (rows, k): mcp_linear_wgrad (rows on the MFMA's contraction axis, fixed-order
+    partial sums) where it takes the shape -- n beyond 256 in column blocks of 256 -- and the library GEMM + a reduce otherwise."""
+    rows, n = gz.shape
+    k = x.shape[1]
+    lib = _lib.load() if gz.is_cuda else None
+    blocks = [(c0, min(256, n - c0)) for c0 in range(0, n, 256)]
+    if lib is None or rows < 2048 or any(lib.mcp_linear_wgrad_workspace_bytes(rows, nb, k) == 0 for _, nb in blocks):
+        return gz.t() @ x, gz.sum(dim=0)
+    gz, x = gz.contiguous(), x.contiguous()
+    dw = torch.empty((n, k), dtype=torch.float32, device=gz.device)
+    db = torch.empty((n,), dtype=torch.float32, device=gz.device)
+    for c0, nb in blocks:
+        need = lib.mcp_linear_wgrad_workspace_bytes(rows, nb, k)
+        ws = torch.empty((need,), dtype=torch.uint8, device=gz.device)
+        _call("mcp_linear_wgrad", gz, rows, nb, k, gz.data_ptr() + 4 * c0, n, _lib.fptr(x), k, dw.data_ptr() + 4 * c0 * k, db.data_ptr() + 4 * c0,
+              ws.data_ptr(), need)
+    return dw, db
+
+
+class _Mlp2Fn(torch.autograd.Function):
+    """mcp_mlp2 (Linear, one-slope PReLU, Linear, + residual) with an explicit backward on the streaming kernels: the hidden
+    activation is rebuilt once (forward kernel), the two input-gradient products run on the forward kernel with transposed weights,
+    the two weight gradients on mcp_linear_wgrad -- instead of autograd over the unfused twin (four library GEMMs on tall, narrow
+    operands: 3.6 ms per training step at the pipeline's shapes)."""
+
+    @staticmethod
+    def forward(ctx, fused, x, res, w1, b1, w2, b2, slope):
+        args = [None if t is None else t.detach() for t in (x, res, w1, b1, w2, b2)]
+        sl = slope.detach() if isinstance(slope, torch.Tensor) else slope
+        out = fused(*args, sl)
+        ctx.slope_is_tensor = isinstance(slope, torch.Tensor)
+        ctx.slope = None if ctx.slope_is_tensor else float(slope)
+        ctx.has_res = res is not None
+        ctx.save_for_backward(x, w1, b1, w2, *( [slope] if ctx.slope_is_tensor else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w1, b1, w2, *rest = ctx.saved_tensors
+        slope = rest[0] if ctx.slope_is_tensor else ctx.slope
+        hdim, cin = w1.shape
+        cout = w2.shape[0]
+        x2 = x.reshape(-1, cin)
+        gy = grad_out.reshape(-1, cout).contiguous()
+        hid = _tall_matmul(x2, w1.t())
+        if b1 is not None:
+            hid = hid + b1
+        pos = hid > 0
+        act = torch.where(pos, hid, hid * slope)
+        g_act = _tall_matmul(gy, w2)                                   # (rows, hidden)
+        dw2, db2 = _wgrad(gy, act)
+        g_hid = torch.where(pos, g_act, g_act * slope)
+        dslope = None
+        if ctx.slope_is_tensor and ctx.needs_input_grad[7]:
+            dslope = (g_act * torch.where(pos, torch.zeros_like(hid), hid)).sum().reshape(slope.shape)
+        dw1, db1 = _wgrad(g_hid, x2)
+        dx = _tall_matmul(g_hid, w1).reshape(x.shape) if ctx.needs_input_grad[1] else None
+        dres = grad_out if ctx.has_res and ctx.needs_input_grad[2] else None
+        return (None, dx, dres, dw1 if ctx.needs_input_grad[3] else None, db1 if (b1 is not None and ctx.needs_input_grad[4]) else None,
+                dw2 if ctx.needs_input_grad[5] else None, db2 if ctx.needs_input_grad[6] else None, dslope)
+
+
 class _LinearFn(torch.autograd.Function):
     """The fused Linear (+ one-slope activation, + residual) with an explicit backward: two GEMMs and a mask taken from the saved
     activation OUTPUT (for 0 <= slope <= 1 the output of act is positive exactly where its argument is), instead of evaluating the
@@ -228,11 +314,49 @@ class _LinearFn(torch.autograd.Function):
             gz = torch.where(act.reshape(-1, n) > 0, gy, gy * ctx.slope)
         else:
             gz = gy
-        dx = (gz @ w).reshape(x.shape) if ctx.needs_input_grad[1] else None
-        dw = gz.t() @ x.reshape(-1, k) if ctx.needs_input_grad[2] else None
-        db = gz.sum(dim=0) if ctx.has_b and ctx.needs_input_grad[3] else None
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dx = _tall_matmul(gz, w).reshape(x.shape)                  # dx = gz W: the forward kernel again, on W^T
+        if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
+            dw, db = _wgrad(gz, x.reshape(-1, k))                      # dW = gz^T x and db in one kernel (csrc/linear_grad.hip)
+            if not (ctx.has_b and ctx.needs_input_grad[3]):
+                db = None
         dres = grad_out if ctx.has_res and ctx.needs_input_grad[5] else None
         return None, dx, dw, db, None, dres
+
+
+class _TorchLinearFn(torch.autograd.Function):
+    """A tall per-point Linear the fused kernel does not take (the 3 -> 32 lift, the 32 -> 3 head: widths that are not multiples
+    of 4) -- the library's forward, but the backward of _LinearFn: the weight gradient of a (rows x 3) operand is otherwise a
+    (3 x rows) x (rows x 32) library GEMM of 300-430 us (round 5 trace) against ~20 for mcp_linear_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        y = torch.nn.functional.linear(x.detach(), w.detach(), None if b is None else b.detach())
+        if slope != 1.0:
+            y = torch.where(y > 0, y, y * slope)
+        ctx.slope, ctx.has_b = float(slope), b is not None
+        ctx.save_for_backward(x, w, y if slope != 1.0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w, act = ctx.saved_tensors
+        n, k = w.shape
+        gy = grad_out.reshape(-1, n)
+        gz = torch.where(act.reshape(-1, n) > 0, gy, gy * ctx.slope) if ctx.slope != 1.0 else gy
+        dx = _tall_matmul(gz, w).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            dw, db = _wgrad(gz, x.reshape(-1, k))
+            if not (ctx.has_b and ctx.needs_input_grad[2]):
+                db = None
+        return dx, dw, db, None
+
+
+def plain_linear(x, w, b, slope=1.0):
+    """act(x W^T + b) on the library's GEMM with the streaming backward kernels (training forwards, tall inputs only)."""
+    return _TorchLinearFn.apply(x, w, b, float(slope))
 
 
 class _PtblockFn(torch.autograd.Function):
@@ -837,6 +961,15 @@ class HipBackend:
         ks = (ctypes.c_int * len(ps))(*[p.shape[1] for p in ps])
         return _lib.load().mcp_linear_packed_floats(n, len(ps), ks) != 0
 
+    def linear_kernel_ok(self, x2d, n):
+        """Whether the fused Linear KERNEL can take (rows, K) -> n at all (capability, not the inference shape policy above): used by
+        the backward products, where the alternative is a library GEMM on a tall, narrow operand."""
+        ps = self._pieces(x2d)
+        if self._NO_LINEAR or ps is None or len(ps) != 1:
+            return False
+        ks = (ctypes.c_int * 1)(ps[0].shape[1])
+        return _lib.load().mcp_linear_packed_floats(n, 1, ks) != 0
+
     # shape policy of the fused Linear (measured optimum; tools/linear_ab.py overrides them on the class)
     _NO_LINEAR = False
     _NO_NARROW = False
@@ -877,7 +1010,12 @@ class HipBackend:
                   None if r2 is None else _lib.fptr(r2), n, _lib.fptr(out), n)
             return out.reshape(*first.shape[:-1], n)
         if isinstance(xs, (tuple, list)) and grad.wants_grad(*xs, w, b, res):
-            return grad.linear_twin(xs, w, b, slope, res)  # training: plain autograd over the concatenation
+            # training: the pieces are concatenated (autograd splits the gradient again) so that the layer takes the explicit
+            # backward below -- the streaming dx / dW kernels -- instead of plain autograd over library GEMMs
+            cat = torch.cat(list(xs), dim=-1)
+            if isinstance(slope, (int, float)) and 0.0 <= slope <= 1.0 and self.linear_supported(cat, w.shape[0], few_rows=False):
+                return _LinearFn.apply(fused, cat, w, b, float(slope), res)
+            return grad.linear_twin(cat, w, b, slope, res)
         if grad.wants_grad(xs, w, b, res) and isinstance(slope, (int, float)) and 0.0 <= slope <= 1.0:
             return _LinearFn.apply(fused, xs, w, b, float(slope), res)
         return grad.run(fused, grad.linear_twin, xs, w, b, slope, res)
@@ -928,6 +1066,8 @@ class HipBackend:
             _call("mcp_mlp2", x_, x2.shape[0], cin, hidden, cout, float(slope_), x2.data_ptr(), x2.stride(0), None if r2 is None else _lib.fptr(r2), cout,
                   _lib.fptr(pk), _lib.fptr(out), cout)
             return out.reshape(*x_.shape[:-1], cout)
+        if grad.wants_grad(x, res, w1, b1, w2, b2, slope) and b2 is not None:
+            return _Mlp2Fn.apply(fused, x, res, w1, b1, w2, b2, slope)
         return grad.run(fused, grad.mlp2_twin, x, res, w1, b1, w2, b2, slope)
 
     def mlp2_supported(self, cin, hidden, cout):

@@ -29,13 +29,22 @@ def gather_points_wrapper(b, c, n, npoints, points, idx, out):
 
 
 def _segments(idx, n):
-    """Stable sort of the scatter positions of every batch element by destination: (order (B,T) int32, seg (B,n+1) int32 CSR
-    offsets).  Scratch comes from torch's allocator here, in the wrapper -- the library itself never allocates."""
+    """Gather positions of every batch element sorted by (destination, position): (order (B,T) int32, seg (B,n+1) int32 CSR
+    offsets) -- mcp_scatter_segments (a counting sort on the small keys).  Scratch comes from torch's allocator here, in the
+    wrapper -- the library itself never allocates."""
     B = idx.shape[0]
-    keys, order = torch.sort(idx.reshape(B, -1), dim=1, stable=True)
-    bounds = torch.arange(n + 1, device=idx.device, dtype=keys.dtype).expand(B, n + 1).contiguous()
-    seg = torch.searchsorted(keys.contiguous(), bounds).int()
-    return order.int().contiguous(), seg.contiguous()
+    flat = idx.reshape(B, -1).int().contiguous()
+    T = flat.shape[1]
+    order = torch.empty((B, T), dtype=torch.int32, device=idx.device)
+    seg = torch.empty((B, n + 1), dtype=torch.int32, device=idx.device)
+    need = _lib.load().mcp_scatter_segments_workspace_bytes(B, T, n)
+    if need == 0:   # more destinations than the kernel's LDS histograms hold: a general stable sort
+        keys, order64 = torch.sort(flat, dim=1, stable=True)
+        bounds = torch.arange(n + 1, device=idx.device, dtype=keys.dtype).expand(B, n + 1).contiguous()
+        return order64.int().contiguous(), torch.searchsorted(keys.contiguous(), bounds).int().contiguous()
+    ws = torch.empty((need,), dtype=torch.uint8, device=idx.device)
+    _call("mcp_scatter_segments", flat, B, T, n, _lib.iptr(flat), _lib.iptr(order), _lib.iptr(seg), ws.data_ptr(), need)
+    return order, seg
 
 
 # The three backward scatters: the reference's kernels add with atomicAdd (sampling_gpu.cu:46-83, group_points_gpu.cu:8-44,

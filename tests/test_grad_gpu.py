@@ -456,6 +456,29 @@ def test_linear_gradients(slope, res_scale):
                   names=["x", "res", "w", "b"])
 
 
+@pytest.mark.parametrize("rows,n,k", [(20000, 64, 32), (16384, 32, 64), (40001, 128, 192), (33000, 256, 64), (70, 64, 64), (50000, 3, 32), (30000, 32, 3), (9000, 40, 67)])
+def test_linear_weight_gradient_kernel_matches_float64_and_repeats(rows, n, k):
+    """mcp_linear_wgrad (csrc/linear_grad.hip): dW = gz^T x and db = column sums of gz with the rows on the MFMA's contraction axis,
+    against float64; ragged row counts (partial last stage), every tiles-per-wave variant; two runs give the same bits."""
+    from mocopci_amd import _lib
+    lib = _lib.load()
+    gz, x = rnd(300, rows, n).to(DEV), rnd(301, rows, k).to(DEV)
+    need = lib.mcp_linear_wgrad_workspace_bytes(rows, n, k)
+    assert need > 0
+    outs = []
+    for _ in range(2):
+        dw, db = torch.empty((n, k), device=DEV), torch.empty((n,), device=DEV)
+        ws = torch.empty((need,), dtype=torch.uint8, device=DEV)
+        ops._call("mcp_linear_wgrad", gz, rows, n, k, _lib.fptr(gz), n, _lib.fptr(x), k, _lib.fptr(dw), _lib.fptr(db), ws.data_ptr(), need)
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    want_w, want_b = gz.double().t() @ x.double(), gz.double().sum(0)
+    scale = float(want_w.abs().max())
+    assert float((outs[0][0].double() - want_w).abs().max()) <= 2e-6 * scale * (rows ** 0.5) / 100 + 1e-4 * scale
+    torch.testing.assert_close(outs[0][1].double(), want_b, rtol=1e-4, atol=1e-3)
+    assert lib.mcp_linear_wgrad_workspace_bytes(1000, 512, 32) == 0     # shapes the kernel does not take report 0: the caller keeps the GEMM
+
+
 def test_chamfer_gradients():
     x, y = cloud(80, 2, 500), cloud(81, 2, 700)
     ob, be = OracleBackend(), ops.backend()

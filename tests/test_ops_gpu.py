@@ -120,6 +120,30 @@ def test_reference_api_backward_scatters_are_deterministic_and_exact():
     assert torch.equal(runs[0].cpu(), orc.three_interpolate_grad(go3, idx3, w3, 64))
 
 
+@pytest.mark.parametrize("B,T,n,hot", [(2, 5000, 64, 0), (3, 40000, 8192, 0), (2, 70000, 300, 5), (1, 17, 1000, 0), (2, 262144, 8192, 3)])
+def test_scatter_segments_is_the_stable_sort(B, T, n, hot):
+    """mcp_scatter_segments (counting sort: count / scan / fill / per-row rank) against torch's stable sort + searchsorted: the same
+    permutation and the same CSR offsets, with short rows (all-pairs ranks), rows of 25..64 (bitonic network), rows longer than 64
+    (chunked) -- `hot` destinations that a third of the positions point at -- and empty rows; two runs give the same bits."""
+    from mocopci_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    idx = torch.randint(0, n, (B, T), generator=g, dtype=torch.int32)
+    if hot:
+        mask = torch.rand(B, T, generator=g) < 0.33
+        idx[mask] = torch.randint(0, hot, (int(mask.sum()),), generator=g, dtype=torch.int32)
+    if n >= 1000:
+        idx[idx == 7] = 8          # an empty row
+    d = idx.to(DEV)
+    order, seg = ops._scatter_segments(d, n)
+    order2, seg2 = ops._scatter_segments(d, n)
+    assert torch.equal(order, order2) and torch.equal(seg, seg2)
+    keys, want = torch.sort(idx.long(), dim=1, stable=True)
+    bounds = torch.arange(n + 1).expand(B, n + 1).contiguous()
+    want_seg = torch.searchsorted(keys.contiguous(), bounds)
+    assert torch.equal(seg.cpu().long(), want_seg)
+    assert torch.equal(order.cpu().long(), want)
+
+
 def test_reference_api_grad_wrappers_add_into_the_callers_buffer():
     """The reference's backward kernels atomicAdd into grad_points (sampling_gpu.cu:46-83, group_points_gpu.cu:8-44,
     interpolate_gpu.cu:120-161): a caller that passes a buffer that already holds something gets base + scatter."""
