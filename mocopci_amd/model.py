@@ -354,7 +354,7 @@ class MoCoPCI(nn.Module):
         independent.  CPU backends run inline."""
         # a training forward runs on one stream (autograd replays it in order) -- except lane 0: the sampling pyramid is a function of
         # the input clouds alone and carries no gradient (TRAIN_PYRAMID_LANE; off when the inputs themselves ask for one)
-        if device.type != "cuda" or (self._live is not None and not (which == 0 and self._train_lane0)):
+        if device.type != "cuda" or (self._live is not None and not (which in (0, 6) and self._train_lane0)):
             return None
         if self.LANE_MAP is not None:
             which = self.LANE_MAP[which]
@@ -1404,23 +1404,30 @@ class MoCoPCI(nn.Module):
         self._live = {**dict(self.named_parameters()), **dict(self.named_buffers())}
         self._mode = (float(self.drop_rate), float(self.attn_drop_rate), float(self.drop_path_rate)) if self.training else None
         self._train_lane0 = self.TRAIN_PYRAMID_LANE and not (xyz1.requires_grad or xyz2.requires_grad)
+        N = xyz1.shape[2]
         try:
             with torch.enable_grad(), ops.backend().cloud_scope():
                 self._sched = Schedule(self, xyz.device)
+                if gt is not None:
+                    # downsampling(), mocopci.py:1099-1104: every ground-truth frame sampled to N/4, N/16 and N/32 points, each from the
+                    # full cloud.  Furthest point sampling is sequential from index 0, so the N/16 and N/32 samples are the first points
+                    # of the N/4 sample (bit for bit), and the frames are independent clouds: one launch instead of nine.  It reads the
+                    # ground truth only and carries no gradient: a schedule node on a lane of its own (a 1.2 ms latency chain on 24 CUs
+                    # that used to run after the decoder, on the critical path), fetched where the lists are assembled below
+                    def gt_down():
+                        with torch.no_grad():
+                            return self.fps_gather(torch.cat([g.transpose(1, 2) for g in gt], dim=0).contiguous(), N // 4)
+                    self._sched.run("gt_down", gt_down)
                 pcs, feats = self.run_encoder(xyz, self._sched)
                 flows_f, flows_b, out_lst = self.run_decoder(pcs, feats, B, train=True)
+                pts = self._sched.get("gt_down") if gt is not None else None
         finally:
             self._live = None
             self._mode = None
-        N = xyz1.shape[2]
         gt_frame = []
         if gt is not None:
             with torch.no_grad():
-                # downsampling(), mocopci.py:1099-1104: every ground-truth frame sampled to N/4, N/16 and N/32 points, each from the
-                # full cloud.  Furthest point sampling is sequential from index 0, so the N/16 and N/32 samples are the first points
-                # of the N/4 sample (bit for bit), and the frames are independent clouds: one launch instead of nine.
                 Bg = gt[0].shape[0]
-                pts = self.fps_gather(torch.cat([g.transpose(1, 2) for g in gt], dim=0).contiguous(), N // 4)
                 for i, g in enumerate(gt):
                     p = pts[i * Bg:(i + 1) * Bg]
                     gt_frame.append([g] + [p[:, :N // d].transpose(1, 2).contiguous() for d in (4, 16, 32)])

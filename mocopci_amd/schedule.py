@@ -17,9 +17,11 @@ import torch
 #        and, once those are done, the decoder's feature-only chains of the same level
 #   4  the level-0 self search (input-only: issued with the pyramid)
 #   5  the refinement stage's sampling -- NOT lane 0: the next batch's pyramid may already be queued there
+#   6  training forwards only: the ground truth's sampling (train.py:131 -> mocopci.py:1081-1083)
 NODE_LANES = {
     "xyz": 0, ("pc", 1): 0, ("pc", 2): 0, ("pc", 3): 0, ("pc", 4): 0, "swap_pc": 0,   # input layout, the four FPS levels, the swapped clouds
     "self_search": 4,
+    "gt_down": 6,                               # training forwards: the ground truth's sampling pyramid (no gradient), beside the encoder
     ("swap_f", 1): 1, ("fus", 1): 1, ("cos", 1): 1, "i3_01": 1,
     ("swap_f", 2): 2, ("fus", 2): 2, ("cos", 2): 2,
     "rep0": 1,                                  # level 0's stacked inputs: four copies beside the level-0 interpolation search

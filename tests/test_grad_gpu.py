@@ -1,8 +1,10 @@
-"""-m gpu: gradients of the fused layers.  Forward in training is the fused HIP kernel; backward differentiates
-the layer's unfused twin (mocopci_amd/grad.py) with the deterministic segmented-reduction scatter.  Each layer's gradients --
-w.r.t. coordinates, features and weights -- are compared with torch autograd on the CPU through the oracle backend's own
-restatement of the layer (float32, plain indexing), and one step of the reference's training objective (train.py:135-160) is
-compared end to end."""
+"""-m gpu: gradients of the fused layers.  Forward in training is the fused HIP kernel; the backward of the fusion layer,
+the D = 64 / 128 cost volumes, the PointConv aggregation, the vector-attention block, the narrow-head attention, the per-point Linear and
+the two-layer MLP is a hand-written kernel (or a composition of the streaming kernels) with the deterministic segmented-reduction
+scatter; the remaining layers (cross D = 256, interp3, wide-head attention) differentiate their unfused twin (mocopci_amd/grad.py).
+Each layer's gradients -- w.r.t. coordinates, features and weights -- are compared with float64 re-derivations or with torch autograd on
+the CPU through the oracle backend's own restatement of the layer; one training iteration is compared with the gradients the REFERENCE
+computes through its own autograd.Functions (tests/golden/train_grad_b1_n1024.npz) and, end to end, with the oracle backend."""
 import pytest
 import torch
 import torch.nn.functional as F
