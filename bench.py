@@ -249,9 +249,13 @@ def roofline_entries(timed, calls, steps, pmc):
             e["traffic"] = p["hbm_bytes_per_launch"]
             e["traffic_source"] = "profiles/r05_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's build, read side doubled per the gfx950 rule)"
             e["traffic_stale"] = PMC_IS_STALE
-        for key in ("valu_busy_frac_of_chip", "mfma_busy_frac_of_chip", "mean_resident_waves_per_simd"):
+        for key in ("valu_busy_frac_of_chip", "mfma_busy_frac_of_chip", "mfma_valu_coexec_frac_of_chip", "simd_issue_busy_frac_of_chip",
+                    "mean_resident_waves_per_simd"):
             if key in p:
                 e[key] = p[key]
+        if "simd_issue_busy_frac_of_chip" in p and unit != "bytes":
+            e["simd_issue_note"] = ("matrix pipe and VALU of a SIMD do not overlap on this chip, within or across waves (profiles/r05_overlap2_probe.txt): a fused "
+                                    "MFMA + VALU kernel is bound by the SUM of its two instruction streams; simd_issue_busy = mfma + valu - coexec is its utilisation")
         if kname == "fps":
             comp = sum(b * (16 * n + 4 * m) for (b, n, m) in calls["fps"]) * steps / launches
             iters = sum(m - 1 for (b, n, m) in calls["fps"]) * steps / launches

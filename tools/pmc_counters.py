@@ -5,7 +5,7 @@
 Each CSV is one pass (gpurun refuses --pmc together with tracing, and FETCH_SIZE / WRITE_SIZE do not fit one pass:
 MI355X_MICROARCH.md, "rocprofv3 PMC slots").  tools/profile_round.sh runs the passes:
     1  FETCH_SIZE                                  2  WRITE_SIZE
-    3  SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
+    3  SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES
        SQ_WAIT_ANY SQ_WAIT_INST_ANY  + GRBM_GUI_ACTIVE
 Units and corrections (same guide, HBM section and the SQ-units row of its constants table):
   * FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies a 128-B request as 64 B for wide coalesced reads, so the read
@@ -104,6 +104,11 @@ def main():
                 e["valu_busy_frac_of_chip"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * N_SIMD)   # VALUBusy, gfx94x formula
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
                 e["mfma_busy_frac_of_chip"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * N_SIMD)   # MfmaUtil, gfx94x formula
+            if "SQ_VALU_MFMA_COEXEC_CYCLES" in c and "valu_busy_frac_of_chip" in e and "mfma_busy_frac_of_chip" in e:
+                # share of the SIMD-cycles in which the matrix pipe OR the VALU works: on this chip the two do not overlap, within or
+                # across waves (tools/peak/overlap2_probe.hip), so for a fused MFMA + VALU kernel THIS is the utilisation of its bound
+                e["mfma_valu_coexec_frac_of_chip"] = c["SQ_VALU_MFMA_COEXEC_CYCLES"] / (cycles * N_SIMD)
+                e["simd_issue_busy_frac_of_chip"] = e["valu_busy_frac_of_chip"] + e["mfma_busy_frac_of_chip"] - e["mfma_valu_coexec_frac_of_chip"]
         out[f] = e
     json.dump(out, open(out_path, "w"), indent=1)
     for f, e in out.items():
@@ -112,7 +117,8 @@ def main():
         print(f"{f:14s} n={e['launches_sampled']:4d} {e['avg_dispatch_us_under_pmc']:9.1f} us"
               + (f"  hbm {e['hbm_bytes_per_launch'] / 1e6:8.2f} MB" if "hbm_bytes_per_launch" in e else "")
               + (f"  valu {e['valu_busy_frac_of_chip']:.3f}" if "valu_busy_frac_of_chip" in e else "")
-              + (f"  mfma {e['mfma_busy_frac_of_chip']:.3f}" if "mfma_busy_frac_of_chip" in e else ""))
+              + (f"  mfma {e['mfma_busy_frac_of_chip']:.3f}" if "mfma_busy_frac_of_chip" in e else "")
+              + (f"  either {e['simd_issue_busy_frac_of_chip']:.3f}" if "simd_issue_busy_frac_of_chip" in e else ""))
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fet
 echo "fetch done"
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o w -- $B > "$out/pmc_write.log" 2>&1
 echo "write done"
-timeout -k 5 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+timeout -k 5 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
     --output-format csv -d "$out/pmc_sq" -o s -- $B > "$out/pmc_sq.log" 2>&1
 echo "sq done"
 python3 -c "import json, bench; json.dump({'csrc_sha256': bench.kernel_sources_digest()}, open('$out/pmc_sources.json', 'w'))"

@@ -10,6 +10,10 @@ steps = 40
 for a in sys.argv[1:]:
     if a.startswith("--steps"):
         steps = int(a.split("=")[1])
+    elif a.startswith("--move="):   # --move=node:lane, e.g. --move="('fus', 3):3" or --move=wf:none -- an entry of schedule.NODE_LANES
+        from mocopci_amd import schedule
+        node, lane = a[7:].rsplit(":", 1)
+        schedule.NODE_LANES[eval(node) if node.startswith("(") else node] = None if lane == "none" else int(lane)
     elif a.startswith("net.LANE_MAP="):   # e.g. net.LANE_MAP=0,1,2,3,0,5: side lanes folded onto fewer HIP streams
         MoCoPCI.LANE_MAP = tuple(int(t) for t in a.split("=")[1].split(","))
     elif a.startswith("net."):
