@@ -260,6 +260,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_wide_kernel(int nq, i
         if (more) {
             stash_k(cur ^ 1);
             fetch(t + 1, v, vs);
+        } else {
+            // Last stage: nothing sits between the S MFMAs and the first vector read of their result when the tile is also full (the
+            // masking below is skipped).  With the accumulators in ordinary VGPRs (-amdgpu-mfma-vgpr-form) this compiler's hazard
+            // recogniser left 5 of the 18 wait states a 16-pass MFMA result needs on that path (tools/isa_lint.py found it; every
+            // other consumer of an MFMA result in the library has its wait states) -- so they are spelled out here, once per launch
+            // and wave.
+            asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
         }
         const int kbase = t * KT;
         if (kbase + KT > nk) {

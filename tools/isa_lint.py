@@ -183,6 +183,15 @@ def lint(path):
                     need = max(need, 2)
                 if ws < need and (base in CHECKED or is_dpp and i.asm):
                     findings.append(f"{where}    reads the result of `{prod.text}` (line {prod.line}) after {ws} wait state(s), needs {need}")
+        elif (i.op.startswith(("v_", "ds_", "global_", "buffer_", "flat_", "scratch_")) and not i.op.startswith("v_mfma")) and i.src:
+            # (round 5) EVERY consumer of a matrix-core result held in ordinary VGPRs, not only the opcodes inline asm can hide: with
+            # -mllvm -amdgpu-mfma-vgpr-form the accumulators are read by vector / LDS / memory instructions directly, and on one path
+            # (a branch over the partial-tile masking of attention_small_kernel) this compiler left 5 wait states where 18 are needed
+            for prod, ws in producers(ins, preds, k, i.src, MAX_LOOKBACK):
+                if prod.op.startswith("v_mfma"):
+                    need = mfma_wait(prod.op)
+                    if ws < need:
+                        findings.append(f"{where}    reads the result of `{prod.text}` (line {prod.line}) after {ws} wait state(s), needs {need}")
         if i.op.startswith(("v_readlane", "v_readfirstlane")) or (i.op.startswith("v_permlane") and "swap" in i.op):
             need = 2 if "swap" in i.op else 1
             for prod, ws in producers(ins, preds, k, i.src, 4):
