@@ -315,6 +315,193 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attention_wide_kernel(int nq, i
     }
 }
 
+// ---- the same attention with the KEYS split over the waves of a workgroup (round 5) --------------------------------------------------
+// Cross_Frame_Att (mocopci.py:499-522) is 16 x 3 problems of 256 queries x 256 keys at head width 256: in the kernel above that is 96
+// workgroups = 384 waves of 8 key stages each, 55 us of f32-MFMA work per wave on a third of the chip's SIMDs (107 us per launch).  Here a
+// workgroup owns 32 queries and its four waves take the 32-key stages w, w + 4, ...: four times the waves, a quarter of the serial MFMA
+// chain each.  A wave stages its K tile, then (in the same LDS buffer, once the S MFMAs have read K) its V tile -- the tiles are not
+// shared between waves any more, so there is no workgroup barrier in the loop; the four partial results (running maximum, row sums,
+// O^T tiles) meet in LDS at the end and wave w finishes the output channels 64 w .. 64 w + 63:
+//     M = max_i m_i,  O = sum_i exp2(m_i - M) O_i / sum_i exp2(m_i - M) l_i        (the usual log-sum-exp merge, waves in order).
+// Same MFMA sequence per (query, key stage) as attention_wide_kernel; the merge changes the order in which the stages' contributions
+// are added, so results agree to rounding (tests: same tolerance against float64), not bit for bit.
+template <int HD>
+struct WideSplitCfg {
+    static constexpr int KT = 32, KS = HD + 1, TD = HD / 32;
+    static constexpr int BUF = KT * KS;                                  // floats per wave: K tile (padded rows) or V tile or the wave's O^T
+    static constexpr size_t LDS_BYTES = (size_t)WAVES * (BUF + 2 * 64) * sizeof(float);
+    static_assert(TD * 16 * 64 <= BUF, "a wave's O^T tiles fit its staging buffer");
+    static_assert(TD % WAVES == 0, "output tiles shared out evenly");
+};
+
+template <int HD>
+__global__ __launch_bounds__(64 * WAVES, 1) void attention_wide_ksplit_kernel(int nq, int nk, const float *__restrict__ q, int qs,
+                                                                              const float *__restrict__ k, int ks, const float *__restrict__ v,
+                                                                              int vs, float scale_log2e, float *__restrict__ out, int os, int kv_shift) {
+    using C = WideSplitCfg<HD>;
+    constexpr int KT = C::KT, KS = C::KS, TD = C::TD, BUF = C::BUF;
+    extern __shared__ __attribute__((aligned(16))) float lds_ws[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    float *buf = lds_ws + wave * BUF;                       // this wave's staging buffer
+    float *ml = lds_ws + WAVES * BUF;                       // [WAVES][2][64]: running maximum, row sum
+    const int head = blockIdx.y, bf = blockIdx.z;
+    const int qi = blockIdx.x * 32 + col;
+    const bool live = qi < nq;
+    q += ((size_t)bf * nq + (live ? qi : 0)) * qs + head * HD;
+    int bkv = bf + kv_shift;
+    if (bkv >= (int)gridDim.z) bkv -= (int)gridDim.z;
+    k += (size_t)bkv * nk * ks + head * HD;
+    v += (size_t)bkv * nk * vs + head * HD;
+
+    float qf[HD / 2];
+#pragma unroll
+    for (int s4 = 0; s4 < HD / 4; ++s4) {
+        const float4 t = *reinterpret_cast<const float4 *>(q + 4 * s4);
+        qf[2 * s4 + 0] = (h ? t.y : t.x) * scale_log2e;
+        qf[2 * s4 + 1] = (h ? t.w : t.z) * scale_log2e;
+    }
+    f32x16 o[TD];
+#pragma unroll
+    for (int d = 0; d < TD; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    // A wave stages a 32-key tile by itself: 32 x HD/4 float4 = 32 per lane, all in flight at once and UNDER the MFMA phase in front of
+    // their use: the V tile is requested before the S MFMAs, the next stage's K tile before the P.V MFMAs (one round trip per tile,
+    // hidden; four dependent round trips of eight loads each, exposed, made the first version of this kernel 85 us)
+    constexpr int F4_ROW = HD / 4, PER_LANE = KT * F4_ROW / 64;
+    float4 pre[PER_LANE];
+    auto issue = [&](int t, const float *src, int stride) {
+#pragma unroll
+        for (int u = 0; u < PER_LANE; ++u) {
+            const int e = u * 64 + lane;
+            const int row = e / F4_ROW, c4 = e % F4_ROW, key = t * KT + row;
+            pre[u] = key < nk ? *reinterpret_cast<const float4 *>(src + (size_t)key * stride + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](bool padded) {
+#pragma unroll
+        for (int u = 0; u < PER_LANE; ++u) {
+            const int e = u * 64 + lane;
+            const int row = e / F4_ROW, c4 = e % F4_ROW;
+            if (padded) {
+                float *dst = &buf[row * KS + c4 * 4];
+                dst[0] = pre[u].x; dst[1] = pre[u].y; dst[2] = pre[u].z; dst[3] = pre[u].w;
+            } else {
+                *reinterpret_cast<float4 *>(&buf[row * HD + c4 * 4]) = pre[u];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int stages = (nk + KT - 1) / KT;
+    if (wave < stages) issue(wave, k, ks);
+    for (int t = wave; t < stages; t += WAVES) {
+        commit(true);                      // this stage's K tile
+        issue(t, v, vs);                   // its V tile: in flight under the S MFMAs
+        const float *ka = &buf[col * KS + h];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < HD / 2; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qf[s], acc, 0, 0, 0);
+            if ((s & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_wave_barrier();   // every lane's K reads are issued; LDS serves a wave's accesses in order: V may overwrite the buffer
+        commit(false);
+        if (t + WAVES < stages) issue(t + WAVES, k, ks);   // the next stage's K tile: in flight under the softmax and the P.V MFMAs
+        const int kbase = t * KT;
+        if (kbase + KT > nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kbase + chan_of(r, h) >= nk) acc[r] = -INFINITY;
+        }
+        float mt = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, acc[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < TD; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = __builtin_amdgcn_exp2f(acc[r] - mn);
+            l += p[r];
+        }
+#pragma unroll
+        for (int d = 0; d < TD; ++d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = buf[chan_of(r, h) * HD + 32 * d + col];
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p[r], o[d], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_wave_barrier();   // V reads issued before the next stage's K tile is written
+    }
+    // ---- the four partial results meet in LDS ----
+    const float lq = l + __shfl_xor(l, 32);   // the query's row sum over this wave's stages (both lane halves)
+#pragma unroll
+    for (int d = 0; d < TD; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[(d * 16 + r) * 64 + lane] = o[d][r];
+    ml[(wave * 2 + 0) * 64 + lane] = m;
+    ml[(wave * 2 + 1) * 64 + lane] = lq;
+    __syncthreads();
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) mm = fmaxf(mm, ml[(w * 2 + 0) * 64 + lane]);
+    float sc[WAVES], lsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const float mw = ml[(w * 2 + 0) * 64 + lane];
+        sc[w] = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw - mm);   // a wave without stages (nk < 32 * WAVES) contributes nothing
+        lsum += sc[w] * ml[(w * 2 + 1) * 64 + lane];
+    }
+    const float inv = 1.0f / lsum;
+    if (live) {
+        float *dst = out + ((size_t)bf * nq + qi) * os + head * HD;
+        constexpr int TPW = TD / WAVES;
+#pragma unroll
+        for (int dd = 0; dd < TPW; ++dd) {
+            const int d = wave * TPW + dd;
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) a += sc[w] * lds_ws[w * BUF + (d * 16 + r) * 64 + lane];
+                res[r] = a * inv;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(dst + 32 * d + 8 * g + 4 * h) = make_float4(res[4 * g], res[4 * g + 1], res[4 * g + 2], res[4 * g + 3]);
+        }
+    }
+}
+
+template <int HD>
+int launch_wide_ksplit(int bf, int nq, int nk, int heads, const float *q, int qs, const float *k, int ks, const float *v, int vs, float sl2,
+                       float *out, int os, int kv_shift, hipStream_t s) {
+    auto kern = attention_wide_ksplit_kernel<HD>;
+    static McpPerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        { const hipError_t attr_e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (attr_e_ != hipSuccess) return (int)attr_e_; }
+        attr_once.done();
+    }
+    hipLaunchKernelGGL(kern, dim3(mcp_divup(nq, 32), heads, bf), dim3(64 * WAVES), WideSplitCfg<HD>::LDS_BYTES, s, nq, nk, q, qs, k, ks, v, vs, sl2,
+                       out, os, kv_shift);
+    return mcp_launch_status();
+}
+
 template <int HD>
 int launch_wide(int bf, int nq, int nk, int heads, const float *q, int qs, const float *k, int ks, const float *v, int vs, float sl2,
                 float *out, int os, int kv_shift, hipStream_t s) {
@@ -353,7 +540,11 @@ int attention_any(int bf, int nq, int nk, int heads, int hd, const float *q, int
     } else {
         rc = hd == 32   ? launch_wide<32>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, kv_shift, s)
              : hd == 64 ? launch_wide<64>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, kv_shift, s)
-                        : launch_wide<256>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, kv_shift, s);
+                        // head width 256: few, long problems -- when the query-stationary form would not cover the chip's 1024 SIMDs and there
+                        // are key stages to share out, the waves of a workgroup split the keys instead
+                        : ((long long)mcp_divup(nq, 32 * WAVES) * heads * bf * WAVES < 1024 && nk >= 32 * WAVES)
+                              ? launch_wide_ksplit<256>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, kv_shift, s)
+                              : launch_wide<256>(bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, out, out_stride, kv_shift, s);
     }
     mcp_prof_end(MCP_KERNEL_ATTENTION, s);
     return rc;
