@@ -149,8 +149,9 @@ def interp3_apply_twin(G, feat, idx3, w3):
     return torch.sum(w3.unsqueeze(-1) * G(feat, idx3), dim=2)
 
 
-def chamfer_twin(G, x, y, ixy, iyx):
+def chamfer_twin(G, x, y, ixy, iyx, per_sample=False):
     """chamfer_loss, models/utils.py:36-45 (pytorch3d defaults): nearest neighbours fixed by the search, squared L2 to them."""
     dxy = ((x - G(y, ixy.unsqueeze(-1)).squeeze(2)) ** 2).sum(-1)
     dyx = ((y - G(x, iyx.unsqueeze(-1)).squeeze(2)) ** 2).sum(-1)
-    return (dxy.mean(1) + dyx.mean(1)).mean()
+    v = dxy.mean(1) + dyx.mean(1)
+    return v if per_sample else v.mean()

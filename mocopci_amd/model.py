@@ -637,13 +637,18 @@ class MoCoPCI(nn.Module):
         B2, N, C = new.shape
         B = B2 // 2
         a = prefix + ".attn_feats"
-        y = self.bn_eval(new, prefix + ".norm1", 1e-5)
-        def heads():  # head slot 0 is dropped and nothing after the attention mixes slots: project only slots 1..3
+        P = self._params()
+        def heads():  # head slot 0 is dropped and nothing after the attention mixes slots: project only slots 1..3; the eval-mode
+            # BatchNorm in front (norm1: y = g x + h per channel) folds into both projections, W (g x + h) + b = (W diag g) x + (W h + b)
             wq, bq, wkv, bkv = self.W(a + ".q"), self.Bv(a + ".q"), self.W(a + ".kv"), self.Bv(a + ".kv")
             sl = lambda t: None if t is None else torch.cat([t[C:4 * C], t[5 * C:8 * C]], dim=0).contiguous()
-            return wq[C:].contiguous(), None if bq is None else bq[C:].contiguous(), sl(wkv), sl(bkv)
-        wq, bq, wkv, bkv = self.derived(("cfa_heads", prefix), heads)
-        q, kv = F.linear(y, wq, bq), F.linear(y, wkv, bkv)                        # (2B,N,3C), (2B,N,6C) = [k | v]
+            wq, bq, wkv, bkv = wq[C:].contiguous(), None if bq is None else bq[C:].contiguous(), sl(wkv), sl(bkv)
+            g = P[prefix + ".norm1.weight"] * torch.rsqrt(P[prefix + ".norm1.running_var"] + 1e-5)
+            hsh = P[prefix + ".norm1.bias"] - P[prefix + ".norm1.running_mean"] * g
+            fold = lambda w, b: ((w * g[None, :]).contiguous(), (w @ hsh + (0 if b is None else b)).contiguous())
+            return (*fold(wq, bq), *fold(wkv, bkv))
+        wq, bq, wkv, bkv = self.derived(("cfa_heads_folded", prefix), heads)
+        q, kv = F.linear(new, wq, bq), F.linear(new, wkv, bkv)                    # (2B,N,3C), (2B,N,6C) = [k | v]
         att = ops.backend().attention_rot(q, kv[..., :3 * C], kv[..., 3 * C:], 3, B, scale=C ** -0.5)     # (2B,N,3C)
         # the sum over the two frames; proj and the MLP act on the last axis only, so the (N, slot) order of the rows is kept as the
         # attention wrote it and only the small (B,N,3,3) result is rearranged (transposing o first cost two copies of it)
@@ -937,7 +942,7 @@ class MoCoPCI(nn.Module):
         w = [t for n in (".fc_delta.0", ".fc_delta.2", ".fc_gamma.0", ".fc_gamma.2") for t in (self.W(prefix + n), self.Bv(prefix + n))]
         packed = None if self._live is not None else self.derived(("ptblock_pack", be.name, prefix), lambda: be.ptblock_pack(*w))
         res = be.ptblock_layer(xyz, qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], idx, w, packed=packed)
-        return self.lin(res, prefix + ".fc2") + feats
+        return self.lin(res, prefix + ".fc2", res=feats)   # the residual inside the Linear's epilogue where the fused kernel takes the shape
 
     def folded_conv_bn(self, conv, bn, eps):
         """1x1 conv followed by eval-mode BatchNorm as one affine map (cached)."""
@@ -1094,11 +1099,15 @@ class MoCoPCI(nn.Module):
         sched.run("up43", up43)
         sched.run(("cos", 3), lambda: ops.backend().knn_cosine(feats[3], f3o, 16))
         f3 = self.ei_crossformer(m + "ei3", feats[3][:B], feats[3][B:], stacked=feats[3])
-        fus = [None, None, None, torch.cat([f3, f3], dim=0)]
+        fus = [None, None, None, None]
 
         self._mark("ei3 done")
         f_l4_3 = sched.get("up43")
-        c3 = torch.cat([feats[3], fus[3], f_l4_3], dim=-1)                         # (2B,256,576)
+        # (2B,256,576) = [encoder | fusion (the same for both frames) | upsampled level 4]: ONE concatenation, the shared fusion features
+        # enter as a broadcast view instead of a stacked copy
+        N3, C3 = feats[3].shape[1], feats[3].shape[2]
+        c3 = torch.cat([feats[3].view(2, B, N3, C3), f3.unsqueeze(0).expand(2, B, N3, f3.shape[-1]), f_l4_3.view(2, B, N3, -1)],
+                       dim=-1).view(2 * B, N3, -1)
         # cross3 (pointconv_util.py:783-791): rows [:B] give feat1_new, rows [B:] give feat2_new
         x = m + "cross3"
         if self._live is None:

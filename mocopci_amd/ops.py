@@ -1076,21 +1076,23 @@ class HipBackend:
 
     _NO_MLP2 = False
 
-    def chamfer(self, x, y):
+    def chamfer(self, x, y, per_sample=False):
         """chamfer_loss (models/utils.py:36-45; pytorch3d defaults): x (B,N,3), y (B,M,3) -> 0-dim tensor.  As a training loss
         (train.py:135-160) it is differentiable w.r.t. both clouds: the nearest neighbours come from the search kernel and the
-        squared distances to them are re-evaluated differentiably."""
+        squared distances to them are re-evaluated differentiably.  per_sample: the (B,) values whose mean that is -- several terms
+        of the objective that share a ground-truth cloud are then ONE call on a stacked batch (training.multiscale_loss)."""
         if grad.wants_grad(x, y):
             x, y = x.contiguous(), y.contiguous()
             ixy = self.knn(x.detach(), y.detach(), 1, mode=MCP_DIST_DIRECT)[..., 0].contiguous()
             iyx = self.knn(y.detach(), x.detach(), 1, mode=MCP_DIST_DIRECT)[..., 0].contiguous()
-            return grad.chamfer_twin(self.group_rows, x, y, ixy, iyx)
+            return grad.chamfer_twin(self.group_rows, x, y, ixy, iyx, per_sample)
         B, N, _ = x.shape
         M = y.shape[1]
         dxy = torch.empty((B, N), dtype=torch.float32, device=x.device)
         dyx = torch.empty((B, M), dtype=torch.float32, device=x.device)
         _call("mcp_chamfer_nn", x, B, N, M, _lib.fptr(x), _lib.fptr(y), _lib.fptr(dxy), _lib.fptr(dyx))
-        return (dxy.mean(1) + dyx.mean(1)).mean()
+        v = dxy.mean(1) + dyx.mean(1)
+        return v if per_sample else v.mean()
 
 
 _backend = HipBackend()

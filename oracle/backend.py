@@ -194,8 +194,10 @@ class OracleBackend:
     def mlp2_supported(self, cin, hidden, cout):
         return True
 
-    def chamfer(self, x, y):
-        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):  # models/utils.py:36-45 with pytorch3d's defaults
+    def chamfer(self, x, y, per_sample=False):
+        """per_sample: the (B,) values whose mean the loss is (several loss terms evaluated as one batch, mocopci_amd/training.py)."""
+        if per_sample or (torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)):  # models/utils.py:36-45 with pytorch3d's defaults
             d = ((x.unsqueeze(2) - y.unsqueeze(1)) ** 2).sum(-1)
-            return (d.min(2)[0].mean(1) + d.min(1)[0].mean(1)).mean()
+            v = d.min(2)[0].mean(1) + d.min(1)[0].mean(1)
+            return v if per_sample else v.mean()
         return torch.tensor(orc.chamfer(x.detach(), y.detach()), dtype=torch.float32)
