@@ -86,7 +86,31 @@ __device__ __forceinline__ uint32_t cloud_key(const float *p, const float *bbox,
     const float top = (float)((1 << (cc.thin < 0 ? bits3 : BITS2)) - 1);
 #pragma unroll
     for (int a = 0; a < 3; ++a) c[a] = (uint32_t)fminf(fmaxf((p[a] - bbox[a]) * cc.inv, 0.f), top);
-    if (cc.thin < 0) return spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+    if (cc.thin < 0) {
+#ifdef MCP_CLOUD_MORTON3D
+        return spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+#else
+        // three axes: the Hilbert curve here too (Skilling's transposition, "Programming the Hilbert curve", 2004: undo the excess
+        // rotations level by level, then Gray-encode), for the same reason as in the plane -- a run of PT consecutive points is one
+        // connected blob instead of the Z-curve's two or three
+        uint32_t x[3] = {c[0], c[1], c[2]};
+        for (uint32_t q = 1u << (bits3 - 1); q > 1; q >>= 1) {
+            const uint32_t pm = q - 1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (x[i] & q) x[0] ^= pm;
+                else { const uint32_t t = (x[0] ^ x[i]) & pm; x[0] ^= t; x[i] ^= t; }
+            }
+        }
+        x[1] ^= x[0];
+        x[2] ^= x[1];
+        uint32_t t = 0;
+        for (uint32_t q = 1u << (bits3 - 1); q > 1; q >>= 1)
+            if (x[2] & q) t ^= q - 1;
+        x[0] ^= t; x[1] ^= t; x[2] ^= t;
+        return (spread10(x[0]) << 2) | (spread10(x[1]) << 1) | spread10(x[2]);
+#endif
+    }
     uint32_t u = cc.thin == 0 ? c[1] : c[0], v = cc.thin == 2 ? c[1] : c[2];
 #ifdef MCP_CLOUD_Z2D
     return spread2_10(u) | (spread2_10(v) << 1);

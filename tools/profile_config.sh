@@ -11,7 +11,7 @@ timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/t
 cp $(find "$out/trace" -name '*kernel_stats.csv' | head -1) "$out/kernel_stats.csv"
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o f -- $B > "$out/pmc_fetch.log" 2>&1
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o w -- $B > "$out/pmc_write.log" 2>&1
-timeout -k 5 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+timeout -k 5 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
     --output-format csv -d "$out/pmc_sq" -o s -- $B > "$out/pmc_sq.log" 2>&1
 python3 tools/pmc_counters.py "$out/pmc.json" $(find "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" -name '*counter_collection.csv') | tee "$out/pmc_summary.txt"
 rm -rf "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" "$out/trace"
