@@ -643,9 +643,12 @@ def c4_pointnet2_launches(x1, dev, reps=20):
                     "LDS tiles of the cloud per query wave with early exit at nsample hits, so small radii scan most of the cloud: VALU-bound, not HBM-bound"})
     sec = _event_time(lambda: pu.three_nn(xyz, centres), reps)
     byt = B * (12 * N + 12 * 2048 + 24 * N)
-    out.append({"kernel": f"three_nn_kernel (mcp_three_nn) n={N} unknown, m=2048 known", "bound": "hbm", "achieved": byt / sec / 1e9, "peak": HBM_PEAK_GBS,
+    out.append({"kernel": f"three_nn (pointnet2_cuda.three_nn_wrapper: 2 x build_cloud_kernel + knn_pruned_kernel<4>, K=3) n={N} unknown, m=2048 known",
+                "bound": "hbm", "achieved": byt / sec / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": byt / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "launches": reps, "avg_launch_us": sec * 1e6,
-                "note": "compulsory bytes B*(12n+12m+24n) (SURVEY 8d) / launch duration; n*m = 33.5 M distance evaluations per cloud: VALU-bound"})
+                "note": "compulsory bytes B*(12n+12m+24n) (SURVEY 8d) / duration of the whole call (the space-ordered copies of both clouds "
+                "are built inside it); the exhaustive three_nn_kernel (n*m = 33.5 M distance evaluations per cloud, the path of smaller "
+                "clouds) took 228 us at this shape (profiles/r04_c4_bench.json)"})
     return out
 
 

@@ -437,6 +437,21 @@ size_t mcp_linear_wgrad_workspace_bytes(long long rows, int n, int k);
 int mcp_linear_wgrad(long long rows, int n, int k, const float *gz, int gz_stride, const float *x, int x_stride, float *dw, float *db,
                      void *workspace, size_t workspace_bytes, mcp_stream_t stream);
 
+/* PReLU (one slope) followed by dropout on the hidden activation of Mlp_T under net.train() (mocopci.py:1558-1565, :1592-1595: `self.act`
+ * then `self.drop`), and its backward, as one elementwise pass each:
+ *     out[i]    = m_i * (z[i] > 0 ? z[i] : a z[i]),      m_i = 1 / (1 - drop_p) for a kept element, 0 for a dropped one
+ *     grad_z[i] = grad_out[i] m_i (z[i] > 0 ? 1 : a),    grad_slope[0] = sum_i grad_out[i] m_i min(z[i], 0)
+ * `slope` points at the layer's slope ON THE DEVICE (the live parameter).  The mask is a counter-based hash of (seed, i): the caller
+ * draws `seed` from its generator per call and passes the same seed to the backward, which regenerates the mask -- only z is kept
+ * between the passes (the reference keeps z, the mask and the dropped activation).  Same distribution as the reference's mask, not the
+ * same draws for a given torch seed (see mcp_attention_small_dropout).  grad_slope is summed in a fixed order (workgroup count a
+ * function of `total` alone): bit-reproducible.  drop_p outside [0, 1): MCP_ERR_BAD_ARG.
+ * workspace: mcp_prelu_dropout_grad_workspace_bytes(total) caller-owned bytes. */
+int mcp_prelu_dropout(long long total, const float *z, const float *slope, float drop_p, unsigned seed, float *out, mcp_stream_t stream);
+size_t mcp_prelu_dropout_grad_workspace_bytes(long long total);
+int mcp_prelu_dropout_grad(long long total, const float *z, const float *slope, const float *grad_out, float drop_p, unsigned seed,
+                           float *grad_z, float *grad_slope, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+
 /* Fused two-layer per-point MLP (Mlp_T of Multi_Frame_Att, mocopci.py:1558-1565 inside :551-575, and the flow heads
  * trans_block / trans_block_2 -> mapping_xyz, :566-567 / :510-511):
  *     out[r, 0:cout] = (res ? res[r] : 0) + b2 + W2 . act(W1 . x[r] + b1),   act(v) = v > 0 ? v : slope * v   (PReLU with one slope)

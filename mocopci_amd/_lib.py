@@ -89,6 +89,9 @@ SIGNATURES = {
     "mcp_linear_as": [ctypes.c_longlong, ctypes.c_longlong, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _p],
     "mcp_scatter_segments_workspace_bytes": [_i, _i, _i],
     "mcp_scatter_segments": [_i, _i, _i, _p, _p, _p, _p, ctypes.c_size_t, _p],
+    "mcp_prelu_dropout": [ctypes.c_longlong, _p, _p, _f, ctypes.c_uint, _p, _p],
+    "mcp_prelu_dropout_grad_workspace_bytes": [ctypes.c_longlong],
+    "mcp_prelu_dropout_grad": [ctypes.c_longlong, _p, _p, _p, _f, ctypes.c_uint, _p, _p, _p, ctypes.c_size_t, _p],
     "mcp_linear_wgrad_workspace_bytes": [ctypes.c_longlong, _i, _i],
     "mcp_linear_wgrad": [ctypes.c_longlong, _i, _i, _p, _i, _p, _i, _p, _p, _p, ctypes.c_size_t, _p],
     "mcp_linear_narrow": [ctypes.c_longlong, _i, _i, _p, _i, _p, _p, _f, _p, _i, _p],
@@ -103,7 +106,8 @@ _RESTYPES = {"mcp_error_string": ctypes.c_char_p, "mcp_fps_workspace_bytes": cty
              "mcp_cross_grad_workspace_bytes": ctypes.c_size_t, "mcp_pointconv_agg_grad_workspace_bytes": ctypes.c_size_t,
              "mcp_fusion_bn_workspace_bytes": ctypes.c_size_t, "mcp_fusion_bn_grad_workspace_bytes": ctypes.c_size_t,
              "mcp_ptblock_grad_workspace_bytes": ctypes.c_size_t, "mcp_attention_small_grad_workspace_bytes": ctypes.c_size_t,
-             "mcp_linear_wgrad_workspace_bytes": ctypes.c_size_t, "mcp_scatter_segments_workspace_bytes": ctypes.c_size_t}
+             "mcp_linear_wgrad_workspace_bytes": ctypes.c_size_t, "mcp_scatter_segments_workspace_bytes": ctypes.c_size_t,
+             "mcp_prelu_dropout_grad_workspace_bytes": ctypes.c_size_t}
 
 _lib = None
 

@@ -685,8 +685,17 @@ class MoCoPCI(nn.Module):
                 # flow tail at widths mlp2 is not built for (C = 256): library GEMM, then PReLU + the (4C -> 3) map as one kernel
                 slope = P[prefix + ".act.weight"] if live else self.derived(("slope", prefix), lambda: float(P[prefix + ".act.weight"]))
                 return be.linear_narrow(F.linear(x, w1, b1), w2, b2, slope)
-            hid = self.dropout(F.prelu(F.linear(x, w1, b1), P[prefix + ".act.weight"]), drop)
-            out = self.dropout(F.linear(hid, w2, b2), drop)
+            def tall(t, w, b):   # as lin(): the streaming kernel where it takes the shape, else the library with the streaming backward
+                if be.linear_supported(t, w.shape[0], few_rows=not live):
+                    return be.linear(t, w, b, 1.0, None)
+                if live and t.is_cuda and torch.is_grad_enabled() and t.numel() // t.shape[-1] >= 16384:
+                    return ops.plain_linear(t, w, b)
+                return F.linear(t, w, b)
+            if drop > 0.0 and self._mode is not None:   # act + drop as one pass each way (mocopci.py:1561-1562)
+                hid = be.prelu_dropout(tall(x, w1, b1), P[prefix + ".act.weight"], drop)
+            else:
+                hid = F.prelu(tall(x, w1, b1), P[prefix + ".act.weight"])
+            out = self.dropout(tall(hid, w2, b2), drop)
             return out if res is None else out + res
         # the PReLU slope: the live parameter in a training forward (it gets its gradient), a cached float otherwise
         slope = P[prefix + ".act.weight"] if live else self.derived(("slope", prefix), lambda: float(P[prefix + ".act.weight"]))

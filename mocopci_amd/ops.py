@@ -74,10 +74,44 @@ class _GroupRowsFn(torch.autograd.Function):
         return _group_rows_grad(grad_out, idx, ctx.n), None
 
 
+_segments_memo = None   # {key: (idx, (order, seg))} while a segments_memo() block is open (backward runs on autograd's own thread,
+                        # so this is process-wide, not thread-local: one backward pass at a time, as in train.py)
+
+
+@contextlib.contextmanager
+def segments_memo():
+    """Around one backward pass: the (order, seg) pair of a gather list is built once and serves every gradient scattered with
+    that list -- the same neighbour list gathers coordinates, features and interpolation operands in several nodes of the graph.
+    The memo holds the list itself, so its storage cannot be handed to another tensor while the block is open."""
+    global _segments_memo
+    outer, _segments_memo = _segments_memo, ({} if _segments_memo is None else _segments_memo)
+    try:
+        yield
+    finally:
+        _segments_memo = outer
+
+
 def _scatter_segments(idx, n):
     """(order, seg) of a gather list (B,...) into rows 0..n-1: the gather positions sorted by destination row (stable) and the row
     boundaries in that order -- the operands of mcp_group_rows_grad_sorted; one pair serves every tensor gathered with the list.
     mcp_scatter_segments: a counting sort on the small keys (csrc/scatter_csr.hip) instead of a general stable key-value sort."""
+    memo = _segments_memo
+    if memo is None:
+        return _build_segments(idx, n)
+    key = (idx.data_ptr(), tuple(idx.shape), tuple(idx.stride()), idx.dtype, idx._version, n, idx.device.index)
+    hit = memo.get(key)
+    if hit is None:
+        hit = memo[key] = (idx, _build_segments(idx, n), torch.cuda.current_stream(idx.device))
+    elif hit[2] != torch.cuda.current_stream(idx.device):   # built on another stream of this backward pass
+        done = torch.cuda.Event()
+        done.record(hit[2])
+        torch.cuda.current_stream(idx.device).wait_event(done)
+        for t in hit[1]:
+            t.record_stream(torch.cuda.current_stream(idx.device))
+    return hit[1]
+
+
+def _build_segments(idx, n):
     B = idx.shape[0]
     T = idx[0].numel()
     flat = idx.reshape(B, T)
@@ -213,6 +247,33 @@ class _AttentionSmallFn(torch.autograd.Function):
         _call("mcp_attention_small_grad", q, BF, Nq, Nk, heads, C // heads, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
               float(ctx.scale), float(ctx.drop_p), int(ctx.seed), _lib.fptr(out), _lib.fptr(grad_out), _lib.fptr(dq), _lib.fptr(dkv), ws.data_ptr(), need)
         return None, dq, dkv, None, None, None, None
+
+
+class _PreluDropFn(torch.autograd.Function):
+    """mcp_prelu_dropout / mcp_prelu_dropout_grad: PReLU (one slope, the live parameter) then dropout, one pass each way; only z is
+    kept for the backward, which regenerates the mask from the seed."""
+
+    @staticmethod
+    def forward(ctx, z, slope, drop_p, seed):
+        z = z.detach().contiguous()
+        slope_shape = slope.shape
+        slope = slope.detach().reshape(1).contiguous()
+        out = torch.empty_like(z)
+        _call("mcp_prelu_dropout", z, z.numel(), _lib.fptr(z), _lib.fptr(slope), float(drop_p), int(seed), _lib.fptr(out))
+        ctx.drop_p, ctx.seed, ctx.slope_shape = drop_p, seed, slope_shape
+        ctx.save_for_backward(z, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        z, slope = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        dz, da = torch.empty_like(z), torch.empty_like(slope)
+        need = _lib.load().mcp_prelu_dropout_grad_workspace_bytes(z.numel())
+        ws = torch.empty((need,), dtype=torch.uint8, device=z.device)
+        _call("mcp_prelu_dropout_grad", z, z.numel(), _lib.fptr(z), _lib.fptr(slope), _lib.fptr(grad_out), float(ctx.drop_p), int(ctx.seed),
+              _lib.fptr(dz), _lib.fptr(da), ws.data_ptr(), need)
+        return dz, da.reshape(ctx.slope_shape), None, None
 
 
 def _tall_matmul(a, w):
@@ -879,6 +940,15 @@ class HipBackend:
         _call(name, q, BF, Nq, Nk, heads, hd, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
               float(scale), out.data_ptr(), C)
         return out
+
+    def prelu_dropout(self, z, slope, drop_p):
+        """dropout(prelu(z, slope), drop_p) of a training forward (Mlp_T's act + drop, mocopci.py:1561-1562) as one pass, with a
+        one-pass backward; slope: the layer's 1-element parameter.  The mask is a counter-based hash seeded from torch's CPU
+        generator per call (reproducible under torch.manual_seed), as in attention()."""
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())  # CPU generator: no device synchronisation
+        if slope.numel() != 1:
+            raise RuntimeError("prelu_dropout: one slope for all channels (nn.PReLU())")
+        return _PreluDropFn.apply(z, slope, float(drop_p), seed)
 
     def attention_rot(self, q, k, v, heads, kv_shift, scale=None):
         """Attention over one stacked batch whose keys / values come from batch element (b + kv_shift) mod BF: q, k, v are

@@ -82,8 +82,25 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     return _call("mcp_ball_query", xyz, b, n, m, float(radius), nsample, _lib.fptr(new_xyz), _lib.fptr(xyz), _lib.iptr(idx))
 
 
+_searcher = None
+
+
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
-    _call("mcp_three_nn", unknown, b, n, m, _lib.fptr(unknown), _lib.fptr(known), _lib.fptr(dist2), _lib.iptr(idx))
+    """The three nearest known points are the K = 3 case of the package's neighbour search in its direct distance form (same
+    fma chain, ties to the lower index: interpolate_gpu.cu:26-49 inserts on strict <).  Large clouds therefore go through the
+    tile-pruned search over space-ordered copies (mcp_build_cloud + mcp_knn_pruned), which reads a few tiles of `known` per query
+    instead of all m points; the copies are scratch from torch's allocator.  Small clouds run the exhaustive mcp_three_nn."""
+    global _searcher
+    from . import ops
+    if m >= ops.HipBackend.PRUNE_MIN_REFS and n >= ops.HipBackend.PRUNE_MIN_QUERIES and max(n, m) <= 65536:
+        if _searcher is None:
+            _searcher = ops.HipBackend()
+        _lib.fptr(dist2), _lib.iptr(idx)  # dtype / device / contiguity of the caller's outputs
+        ks, kperm, boxes = _searcher._build_cloud(known)
+        us, uperm, _ = _searcher._build_cloud(unknown)
+        return _call("mcp_knn_pruned", unknown, b, n, m, 3, ops.MCP_DIST_DIRECT, _lib.fptr(us), _lib.iptr(uperm), _lib.fptr(ks),
+                     _lib.iptr(kperm), _lib.fptr(boxes), _lib.iptr(idx), _lib.fptr(dist2))
+    return _call("mcp_three_nn", unknown, b, n, m, _lib.fptr(unknown), _lib.fptr(known), _lib.fptr(dist2), _lib.iptr(idx))
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):

@@ -60,7 +60,8 @@ def train_step(net, optimizer, xyz1, xyz2, gt, clip=2.0):
     frames_f, frames_b, gt_frame, out_lst = net(xyz1, xyz2, gt, None, True)
     loss, parts = multiscale_loss(frames_f, frames_b, gt_frame, out_lst, gt)
     optimizer.zero_grad()
-    loss.backward()
+    with ops.segments_memo():
+        loss.backward()
     torch.nn.utils.clip_grad_norm_(net.parameters(), clip)
     optimizer.step()
     return float(loss.detach()), {k: float(v.detach()) for k, v in parts.items()}

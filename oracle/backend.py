@@ -191,6 +191,10 @@ class OracleBackend:
         out = torch.nn.functional.linear(torch.where(hid > 0, hid, hid * slope), w2, b2)
         return out if res is None else out + res
 
+    def prelu_dropout(self, z, slope, drop_p):
+        """Mlp_T's act + drop in a training forward (mocopci.py:1561-1562)."""
+        return torch.nn.functional.dropout(torch.nn.functional.prelu(z, slope.reshape(-1)), drop_p, training=True)
+
     def mlp2_supported(self, cin, hidden, cout):
         return True
 

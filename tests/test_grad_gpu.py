@@ -370,6 +370,41 @@ def test_attention_dropout_kernels_match_the_dense_formulation_under_the_same_ma
     assert torch.equal(o1, o2) and not torch.equal(o1, o3)
 
 
+@pytest.mark.parametrize("shape", [(3, 1000, 256), (7, 33), (4099,)])
+def test_prelu_dropout_kernels_match_torch_under_the_same_mask(shape):
+    """mcp_prelu_dropout and its backward (Mlp_T's act + drop under net.train(), mocopci.py:1561-1562): the mask is a counter-based hash
+    of (seed, element index), rebuilt here with the same integer arithmetic; output is exact, dz exact, the slope gradient within fp32
+    summation error of float64 and the same bits on every call; kept fraction = 1 - p."""
+    be = ops.backend()
+    p, seed, M = 0.25, 987654321, 0xFFFFFFFF
+    z, g = rnd(410, *shape).to(DEV), rnd(411, *shape).to(DEV)
+    slope = torch.tensor([0.37], device=DEV)
+    i = torch.arange(z.numel(), device=DEV, dtype=torch.int64)
+    x = (seed ^ ((i * 0x9E3779B1) & M)) & M          # element indices below 2^32: the high half contributes 0
+    x = x ^ (x >> 16); x = (x * 0x7FEB352D) & M; x = x ^ (x >> 15); x = (x * 0x846CA68B) & M; x = x ^ (x >> 16)
+    keep = (x >= int(p * 4294967296.0)).reshape(shape)
+    if z.numel() > 100000:
+        assert abs(float(keep.double().mean()) - (1.0 - p)) < 5e-3
+    inv = torch.tensor(1.0 / (1.0 - p), dtype=torch.float64).float().to(DEV)
+    zl, sl = z.clone().requires_grad_(True), slope.clone().requires_grad_(True)
+    out = ops._PreluDropFn.apply(zl, sl, p, seed)
+    want_out = torch.where(z > 0, z, slope * z) * torch.where(keep, inv, torch.zeros_like(inv))
+    assert torch.equal(out, want_out)
+    dz, da = torch.autograd.grad(out, (zl, sl), g)
+    gm = g * torch.where(keep, inv, torch.zeros_like(inv))
+    assert torch.equal(dz, torch.where(z > 0, gm, slope * gm))
+    want_da = float((gm.double() * z.double().clamp(max=0)).sum())
+    assert da.shape == slope.shape and abs(float(da) - want_da) <= 1e-5 * float((gm.double() * z.double().clamp(max=0)).abs().sum()) + 1e-6
+    out2 = ops._PreluDropFn.apply(zl, sl, p, seed)
+    assert torch.equal(torch.autograd.grad(out2, (sl,), g)[0], da)                     # fixed summation order
+    assert not (dz[~keep] != 0).any()                                                   # nothing leaks through dropped elements
+    torch.manual_seed(5); o1 = be.prelu_dropout(z, slope, p)
+    torch.manual_seed(5); o2 = be.prelu_dropout(z, slope, p)
+    torch.manual_seed(6); o3 = be.prelu_dropout(z, slope, p)
+    assert torch.equal(o1, o2) and (z.numel() < 64 or not torch.equal(o1, o3))
+    assert torch.equal(ops._PreluDropFn.apply(z, slope, 0.0, 1), torch.where(z > 0, z, slope * z))   # p = 0: plain PReLU
+
+
 def test_ptblock_backward_kernel_matches_the_unfused_block_and_repeats_bit_for_bit():
     """mcp_ptblock_grad against autograd over the unfused block (grad.ptblock_twin) on the device: q, k, v as slices of one packed
     projection (row stride 192), an odd point count (the last wave holds one point); two runs give identical bits.  Points with a
@@ -608,6 +643,9 @@ def test_backward_entry_points_reject_bad_arguments_and_handle_tiny_batches():
     q = f(1, 64, 96)
     assert lib.mcp_attention_small_grad(1, 64, 64, 8, 12, P(q), 96, P(q), 96, P(q), 96, 1.0, 0.0, 0, P(q), P(q), P(q), P(q), P(ws), ws.numel(), st) == 10002
     assert lib.mcp_attention_small_dropout(1, 64, 64, 8, 8, P(q), 64, P(q), 64, P(q), 64, 1.0, 1.5, 0, P(q), st) == 10001   # drop_p outside [0, 1)
+    assert lib.mcp_prelu_dropout(64, P(q), P(q), 1.0, 0, P(q), st) == 10001                                                # likewise
+    assert lib.mcp_prelu_dropout_grad(64, P(q), P(q), P(q), 0.5, 0, P(q), P(q), P(q), 0, st) == 10001                      # workspace too small
+    assert lib.mcp_prelu_dropout(0, P(q), P(q), 0.5, 0, P(q), st) == 10001
     torch.cuda.synchronize()
     # tiny batches through the public operators
     n = 40

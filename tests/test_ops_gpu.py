@@ -180,6 +180,20 @@ def test_ball_query_bit_exact(radius, nsample):
         assert int(want.abs().sum()) == 0  # empty balls stay zero (pre-zeroed idx)
 
 
+def test_three_nn_ties_on_both_paths():
+    """Coordinates on a coarse grid (many equal distances, duplicate points): the pruned search of large clouds and the exhaustive
+    kernel of small ones both give the reference's answer -- strict < insertion, the lower index wins (interpolate_gpu.cu:26-49)."""
+    from mocopci_amd import pointnet2_cuda
+    for n, m in ((4096, 2048), (1024, 2048), (4096, 1024)):
+        unknown, known = (cloud(31, 2, n) * 2).round() / 2, (cloud(32, 2, m) * 2).round() / 2
+        wd, wi = orc.three_nn(unknown, known)
+        d2 = torch.empty(2, n, 3, device=DEV)
+        i2 = torch.empty(2, n, 3, dtype=torch.int32, device=DEV)
+        pointnet2_cuda.three_nn_wrapper(2, n, m, unknown.to(DEV), known.to(DEV), d2, i2)
+        assert torch.equal(i2.cpu(), wi), (n, m)
+        assert torch.equal(torch.sqrt(d2.cpu()), wd), (n, m)
+
+
 @pytest.mark.parametrize("n,m", [(8192, 2048), (1000, 300), (50, 2), (7, 1)])
 def test_three_nn_and_interpolate(n, m):
     unknown, known = cloud(21, 2, n), cloud(22, 2, m)
