@@ -177,6 +177,43 @@ __global__ __launch_bounds__(BLK) void group_rows_grad_sorted_kernel(int n, int 
     }
 }
 
+// Narrow rows (c <= 4: the coordinate gradients, c = 3): the kernel above gives each CHANNEL a thread that walks the whole segment
+// alone -- three dependent 4-byte gathers per entry, one entry after the other (108 us per launch in the round-5 training trace, 31
+// launches per step).  Here NARROW_SUB lanes share a destination row: lane l takes entries lo + l, lo + l + NARROW_SUB, ... with all c
+// channels of an entry, and the lanes' partial sums are added by a butterfly (a + b is commutative bit for bit, so every lane ends
+// with the same bits): a fixed order again, an eighth of the serial chain.
+constexpr int NARROW_SUB = 8;
+__global__ __launch_bounds__(BLK) void group_rows_grad_sorted_narrow_kernel(int n, int c, int t, long long rows, const float *__restrict__ grad_out,
+                                                                            const int *__restrict__ order, const int *__restrict__ seg,
+                                                                            float *__restrict__ grad_points) {
+    const int l = threadIdx.x & (NARROW_SUB - 1);
+    long long row = ((long long)blockIdx.x * BLK + threadIdx.x) / NARROW_SUB;   // b * n + destination
+    const long long stride = (long long)gridDim.x * (BLK / NARROW_SUB);
+    for (; row < rows; row += stride) {
+        const int b = (int)mcp_div(row, n, mcp_fits32(rows)), d = (int)(row - (long long)b * n);
+        const int *sg = seg + (long long)b * (n + 1) + d;
+        const int lo = sg[0], hi = sg[1];
+        const int *ord = order + (long long)b * t;
+        const float *src = grad_out + (long long)b * t * c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int j = lo + l; j < hi; j += NARROW_SUB) {
+            const float *e = src + (long long)ord[j] * c;
+            a0 += e[0];
+            if (c > 1) a1 += e[1];
+            if (c > 2) a2 += e[2];
+            if (c > 3) a3 += e[3];
+        }
+#pragma unroll
+        for (int o = NARROW_SUB / 2; o > 0; o >>= 1) {
+            a0 += __shfl_xor(a0, o, NARROW_SUB);
+            a1 += __shfl_xor(a1, o, NARROW_SUB);
+            a2 += __shfl_xor(a2, o, NARROW_SUB);
+            a3 += __shfl_xor(a3, o, NARROW_SUB);
+        }
+        if (l < c) grad_points[row * c + l] = l == 0 ? a0 : l == 1 ? a1 : l == 2 ? a2 : a3;
+    }
+}
+
 // K4  ball_query_gpu.cu:9-45.  The reference gives one thread per centre a serial scan of all N points with an
 // early break.  Here a WAVE owns a centre: lane l tests points 64*i + l (coalesced reads), the hit mask of each step
 // is a ballot, and a hit's output slot is (hits so far) + (hits in lower lanes) -- exactly the reference's index
@@ -446,6 +483,13 @@ MCP_EXPORT int mcp_group_rows_grad(int b, int n, int c, int t, const float *grad
 MCP_EXPORT int mcp_group_rows_grad_sorted(int b, int n, int c, int t, const float *grad_out, const int *order, const int *seg,
                                           float *grad_points, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && c > 0 && t > 0 && grad_out && order && seg && grad_points);
+    if (c <= 4) {
+        const long long rows = (long long)b * n;
+        const unsigned grid = (unsigned)min((rows * NARROW_SUB + BLK - 1) / BLK, 16384LL);
+        hipLaunchKernelGGL(group_rows_grad_sorted_narrow_kernel, dim3(grid), dim3(BLK), 0, (hipStream_t)stream, n, c, t, rows, grad_out, order, seg,
+                           grad_points);
+        return mcp_launch_status();
+    }
     const bool vec4 = (c % 4 == 0) && !((((uintptr_t)grad_out) | ((uintptr_t)grad_points)) & 15);
     const long long total = (long long)b * n * (vec4 ? c / 4 : c);
     const unsigned grid = (unsigned)min((long long)mcp_divup((unsigned)min(total, (long long)0x7fffffff), BLK), 16384LL);

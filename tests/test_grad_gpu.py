@@ -50,16 +50,24 @@ def compare_grads(fn_hip, fn_cpu, tensors, int_args=(), rtol=2e-4, names=None):
         assert err <= rtol * scale + 2e-5, f"grad {label}: max err {err:.2e}, gradient scale {scale:.2e}"
 
 
-def test_group_rows_gradient_is_deterministic_and_exact():
-    pts = rnd(1, 3, 700, 35).to(DEV).requires_grad_(True)
-    idx = torch.randint(0, 700, (3, 900, 16), generator=torch.Generator().manual_seed(2), dtype=torch.int32).to(DEV)
-    g = rnd(3, 3, 900, 16, 35).to(DEV)
+@pytest.mark.parametrize("C", [35, 64, 3, 1, 2, 4])
+def test_group_rows_gradient_is_deterministic_and_exact(C):
+    """Wide rows (one thread per channel or channel quad walks the segment) and narrow ones (C <= 4, the coordinate gradients: eight
+    lanes share a destination); a third of the gathers hit three hot rows (segments of ~1600 entries), some rows are never gathered."""
+    pts = rnd(1, 3, 700, C).to(DEV).requires_grad_(True)
+    gen = torch.Generator().manual_seed(2)
+    idx = torch.randint(0, 650, (3, 900, 16), generator=gen, dtype=torch.int32)
+    hot = torch.rand(3, 900, 16, generator=gen) < 0.33
+    idx[hot] = torch.randint(0, 3, (int(hot.sum()),), generator=gen, dtype=torch.int32) * 7
+    idx = idx.to(DEV)
+    g = rnd(3, 3, 900, 16, C).to(DEV)
     be = ops.backend()
     grads = [torch.autograd.grad(be.group_rows(pts, idx), pts, g)[0] for _ in range(3)]
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])          # segmented reduction: same bits every run
-    want = torch.zeros(3, 700, 35, dtype=torch.float64)
+    want = torch.zeros(3, 700, C, dtype=torch.float64)
     want.index_put_((torch.arange(3).view(3, 1, 1).expand(3, 900, 16), idx.cpu().long()), g.cpu().double(), accumulate=True)
-    torch.testing.assert_close(grads[0].cpu().double(), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(grads[0].cpu().double(), want, rtol=1e-5, atol=2e-4)   # hot rows: ~1600 addends of O(1) in fp32
+    assert not grads[0][:, 650:].any()
 
 
 @pytest.mark.parametrize("n,s,d", [(256, 256, 32), (1024, 256, 64)])
