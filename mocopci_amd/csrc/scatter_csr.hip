@@ -13,7 +13,8 @@
 //   fill    a workgroup hands out the slots of its chunk from cursors in LDS (atomic with return: the order inside a chunk's share
 //           of a row is whatever the hardware served) ...
 //   rank    ... and one wave per destination puts its row in ascending position order: all-pairs ranks for short rows, a 64-lane
-//           bitonic network for longer ones, chunked all-pairs beyond 64.
+//           bitonic network (1 or 4 registers per lane) up to 256 entries; longer rows are queued and sorted share by share
+//           (csr_long_kernel).
 // The result is the stable sort's, bit for bit, whatever the atomics did.
 #include "common.h"
 
@@ -166,20 +167,27 @@ __global__ __launch_bounds__(256) void csr_rank_kernel(int t, int n, const int *
 }
 
 // the queued long rows (a point that is everybody's neighbour: the refined cloud of an untrained network is a blob whose surface
-// points sit in thousands of lists): a workgroup per row, bitonic sort in LDS; beyond LONG_LDS entries all-pairs ranks from memory
-__global__ __launch_bounds__(256) void csr_long_kernel(int t, int n, const int *__restrict__ seg, const int *__restrict__ slots, int *__restrict__ order,
-                                                     const int *__restrict__ long_list, int long_cap) {
+// points sit in thousands of lists).  A row's slots were handed out chunk by chunk (hist[g][d] = first slot of chunk g's share, the
+// scan's output, which fill only copied), and every position of chunk g is below every position of chunk g + 1: the CHUNKS shares
+// are sorted independently -- one workgroup per (row, chunk) task, bitonic sort in LDS; a share beyond LONG_LDS entries (one row
+// holding a whole chunk of a very long list) falls back to all-pairs ranks from memory.  (Sorting a 5000-entry row whole took one
+// workgroup 91 passes over 8192 LDS slots; its 16 shares of ~300 take 45 passes over 512 each, side by side.)
+__global__ __launch_bounds__(256) void csr_long_kernel(int t, int n, const int *__restrict__ seg, const int *__restrict__ hist,
+                                                     const int *__restrict__ slots, int *__restrict__ order, const int *__restrict__ long_list,
+                                                     int long_cap) {
     __shared__ int buf[LONG_LDS];
     const int tid = threadIdx.x;
-    const int rows = min(long_list[0], long_cap);
-    for (int q = blockIdx.x; q < rows; q += gridDim.x) {
-        const int b = long_list[1 + 2 * q], d = long_list[2 + 2 * q];
-        const int *sb = seg + (size_t)b * (n + 1);
-        const int base = sb[d], len = sb[d + 1] - base;
+    const int tasks = min(long_list[0], long_cap) * CHUNKS;
+    for (int q = blockIdx.x; q < tasks; q += gridDim.x) {
+        const int b = long_list[1 + 2 * (q / CHUNKS)], d = long_list[2 + 2 * (q / CHUNKS)], g = q % CHUNKS;
+        const int *hb = hist + (size_t)b * CHUNKS * n + d;
+        const int base = hb[(size_t)g * n];
+        const int len = (g + 1 < CHUNKS ? hb[(size_t)(g + 1) * n] : seg[(size_t)b * (n + 1) + d + 1]) - base;
         const int *src = slots + (size_t)b * t + base;
         int *dst = order + (size_t)b * t + base;
+        if (len <= 0) continue;   // workgroup-uniform
         if (len <= LONG_LDS) {
-            int p2 = 512;
+            int p2 = 64;
             while (p2 < len) p2 <<= 1;
             for (int e = tid; e < p2; e += 256) buf[e] = e < len ? src[e] : 0x7FFFFFFF;
             __syncthreads();
@@ -243,6 +251,6 @@ MCP_EXPORT int mcp_scatter_segments(int b, int t, int n, const int *idx, int *or
     hipLaunchKernelGGL(csr_scan_kernel, dim3(b), dim3(1024), 0, s, n, hist, seg);
     hipLaunchKernelGGL(csr_fill_kernel, dim3(CHUNKS, b), dim3(CT), lds, s, t, n, per, idx, hist, slots);
     hipLaunchKernelGGL(csr_rank_kernel, dim3((n + 3) / 4, b), dim3(256), 0, s, t, n, seg, slots, order, long_list, cap);
-    hipLaunchKernelGGL(csr_long_kernel, dim3(512), dim3(256), 0, s, t, n, seg, slots, order, long_list, cap);
+    hipLaunchKernelGGL(csr_long_kernel, dim3(1024), dim3(256), 0, s, t, n, seg, hist, slots, order, long_list, cap);
     return mcp_launch_status();
 }

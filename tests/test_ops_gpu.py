@@ -120,11 +120,13 @@ def test_reference_api_backward_scatters_are_deterministic_and_exact():
     assert torch.equal(runs[0].cpu(), orc.three_interpolate_grad(go3, idx3, w3, 64))
 
 
-@pytest.mark.parametrize("B,T,n,hot", [(2, 5000, 64, 0), (3, 40000, 8192, 0), (2, 70000, 300, 5), (1, 17, 1000, 0), (2, 262144, 8192, 3)])
+@pytest.mark.parametrize("B,T,n,hot", [(2, 5000, 64, 0), (3, 40000, 8192, 0), (2, 70000, 300, 5), (1, 17, 1000, 0), (2, 262144, 8192, 3), (1, 1048576, 2, 0)])
 def test_scatter_segments_is_the_stable_sort(B, T, n, hot):
     """mcp_scatter_segments (counting sort: count / scan / fill / per-row rank) against torch's stable sort + searchsorted: the same
     permutation and the same CSR offsets, with short rows (all-pairs ranks), rows of 25..64 (bitonic network), rows longer than 64
-    (chunked) -- `hot` destinations that a third of the positions point at -- and empty rows; two runs give the same bits."""
+    (four registers per lane), rows beyond 256 -- `hot` destinations that a third of the positions point at: sorted chunk share by
+    chunk share in LDS; two destinations for a million positions: shares beyond the LDS buffer -- and empty rows; two runs give the
+    same bits."""
     from mocopci_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + T)
     idx = torch.randint(0, n, (B, T), generator=g, dtype=torch.int32)
