@@ -268,6 +268,7 @@ class MoCoPCI(nn.Module):
 
     TRAIN_PYRAMID_LANE = True   # training forwards: the encoder's FPS chain on side lane 0, beside the level-0 layers
     _train_lane0 = False
+    TRAIN_LANES = (0, 4, 5, 6)
     SDPA_DROPOUT = True         # net.train() on the GPU: attention dropout inside the library's fused attention kernel
     CHECKPOINT_BYTES = 1 << 30  # net.train() forwards: unfused blocks whose intermediates exceed this are recomputed in the backward, in chunks of about this size
 
@@ -352,9 +353,10 @@ class MoCoPCI(nn.Module):
         features (schedule.NODE_LANES).  4: the level-0 self search.  5: the refinement stage's FPS (a lane of its own: the NEXT batch's
         pyramid may already be queued on lane 0).  One set per caller stream, so forwards issued on different streams stay
         independent.  CPU backends run inline."""
-        # a training forward runs on one stream (autograd replays it in order) -- except lane 0: the sampling pyramid is a function of
-        # the input clouds alone and carries no gradient (TRAIN_PYRAMID_LANE; off when the inputs themselves ask for one)
-        if device.type != "cuda" or (self._live is not None and not (which in (0, 6) and self._train_lane0)):
+        # a training forward runs on one stream (autograd replays it in order) -- except the lanes of TRAIN_LANES, whose nodes only
+        # produce INDICES (no gradient, no backward node): the sampling pyramids of the inputs and the ground truth, the level-0 self
+        # search, the refinement stage's sampling (TRAIN_PYRAMID_LANE; off when the inputs themselves ask for a gradient)
+        if device.type != "cuda" or (self._live is not None and not (which in self.TRAIN_LANES and self._train_lane0)):
             return None
         if self.LANE_MAP is not None:
             which = self.LANE_MAP[which]
@@ -1226,7 +1228,10 @@ class MoCoPCI(nn.Module):
         # refinement stage's PointConvD, after the sampling -- a node beside the warped clouds' self search
         sched.run("wf", lambda: self.conv1d_block(f0 + up_flow @ self.area_matrix(3, f0.shape[-1], dev), m + "rlevel0"), reads=(f0,))
         # the refinement stage's sampling: a 1.2-1.4 ms latency chain on 24 CUs
-        sched.run("refine_fps", lambda: self.fps_gather(warped, 2048, return_idx=True))
+        if train:   # the index chain alone goes to the lane (no gradient); the gather that carries the gradient to `warped` stays here
+            sched.run("refine_fps", lambda: ops.backend().fps(warped.detach(), 2048))
+        else:
+            sched.run("refine_fps", lambda: self.fps_gather(warped, 2048, return_idx=True))
         idx_self = ops.backend().knn(warped, warped, 32)      # fusion's self search: independent of the refine branch
         be = ops.backend()
         like = warped.shape[0] * warped.shape[1]   # kernels as for every candidate centre (what the speculative form computes): same bits
@@ -1243,7 +1248,7 @@ class MoCoPCI(nn.Module):
             dfeat = self.pointconv(m + "level1", warped, down, sched.get("wf"), idx=self.sampled_neighbours(idx_self, sel), like_rows=like)
             shape = self.transformer_block(m + "shape1", dfeat, down, idx=sched.get("knn_down"), like_rows=like)
             upf = be.interp3_apply(shape, *sched.get("i3_refine"))
-        elif sched.lane("refine_fps") is not None:
+        elif sched.lane("refine_fps") is not None and not train:
             # same speculation as in the encoder: PointConvD of EVERY candidate centre and the Point-Transformer's four
             # per-point projections are computed while the sampling runs, the sampled rows are gathered afterwards
             t = m + "shape1"
@@ -1258,7 +1263,11 @@ class MoCoPCI(nn.Module):
             upf = be.interp3_apply(shape, *sched.get("i3_refine"))
         else:
             # down = warped[sel]: its 32 nearest in warped are rows of the self search the fusion stage needs anyway
-            down, sel = sched.get("refine_fps")
+            if train:
+                sel = sched.get("refine_fps")
+                down = be.group_rows(warped, sel)
+            else:
+                down, sel = sched.get("refine_fps")
             dfeat = self.pointconv(m + "level1", warped, down, sched.get("wf"), idx=self.sampled_neighbours(idx_self, sel))
             shape = self.transformer_block(m + "shape1", dfeat, down)
             upf = ops.backend().interp3(warped, down, shape)

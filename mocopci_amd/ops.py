@@ -249,6 +249,23 @@ class _AttentionSmallFn(torch.autograd.Function):
         return None, dq, dkv, None, None, None, None
 
 
+def _prelu_drop_fwd(z, slope, drop_p=0.0, seed=0):
+    """m * prelu(z, slope): slope a 1-element device tensor; drop_p = 0: plain PReLU (mcp_prelu_dropout)."""
+    out = torch.empty_like(z)
+    _call("mcp_prelu_dropout", z, z.numel(), _lib.fptr(z), _lib.fptr(slope), float(drop_p), int(seed), _lib.fptr(out))
+    return out
+
+
+def _prelu_drop_bwd(z, slope, grad_out, drop_p=0.0, seed=0):
+    """(dz, dslope (1,)) of the above in one pass over z and grad_out (mcp_prelu_dropout_grad; dslope summed in a fixed order)."""
+    dz, da = torch.empty_like(z), torch.empty((1,), dtype=torch.float32, device=z.device)
+    need = _lib.load().mcp_prelu_dropout_grad_workspace_bytes(z.numel())
+    ws = torch.empty((need,), dtype=torch.uint8, device=z.device)
+    _call("mcp_prelu_dropout_grad", z, z.numel(), _lib.fptr(z), _lib.fptr(slope), _lib.fptr(grad_out), float(drop_p), int(seed),
+          _lib.fptr(dz), _lib.fptr(da), ws.data_ptr(), need)
+    return dz, da
+
+
 class _PreluDropFn(torch.autograd.Function):
     """mcp_prelu_dropout / mcp_prelu_dropout_grad: PReLU (one slope, the live parameter) then dropout, one pass each way; only z is
     kept for the backward, which regenerates the mask from the seed."""
@@ -256,36 +273,33 @@ class _PreluDropFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, slope, drop_p, seed):
         z = z.detach().contiguous()
-        slope_shape = slope.shape
+        ctx.drop_p, ctx.seed, ctx.slope_shape = drop_p, seed, slope.shape
         slope = slope.detach().reshape(1).contiguous()
-        out = torch.empty_like(z)
-        _call("mcp_prelu_dropout", z, z.numel(), _lib.fptr(z), _lib.fptr(slope), float(drop_p), int(seed), _lib.fptr(out))
-        ctx.drop_p, ctx.seed, ctx.slope_shape = drop_p, seed, slope_shape
         ctx.save_for_backward(z, slope)
-        return out
+        return _prelu_drop_fwd(z, slope, drop_p, seed)
 
     @staticmethod
     def backward(ctx, grad_out):
         z, slope = ctx.saved_tensors
-        grad_out = grad_out.contiguous()
-        dz, da = torch.empty_like(z), torch.empty_like(slope)
-        need = _lib.load().mcp_prelu_dropout_grad_workspace_bytes(z.numel())
-        ws = torch.empty((need,), dtype=torch.uint8, device=z.device)
-        _call("mcp_prelu_dropout_grad", z, z.numel(), _lib.fptr(z), _lib.fptr(slope), _lib.fptr(grad_out), float(ctx.drop_p), int(ctx.seed),
-              _lib.fptr(dz), _lib.fptr(da), ws.data_ptr(), need)
+        dz, da = _prelu_drop_bwd(z, slope, grad_out.contiguous(), ctx.drop_p, ctx.seed)
         return dz, da.reshape(ctx.slope_shape), None, None
 
 
-def _tall_matmul(a, w):
-    """a (rows, n) @ w (n, k) for rows >> n, k (the input gradient of a per-point Linear): the streaming forward kernel on w^T where it
-    is built for the shape (the library GEMM takes ~160 us for 196608 x 64 @ 64 x 32 against ~30), the library otherwise."""
+def _leaky_grad(gy, y, slope):
+    """gy * act'(z) of a one-slope activation (0 <= slope <= 1) from its OUTPUT y (y > 0 exactly where z > 0): one pass."""
+    return torch.ops.aten.leaky_relu_backward(gy, y, float(slope), True)
+
+
+def _tall_matmul(a, w, bias=None):
+    """a (rows, n) @ w (n, k) (+ bias) for rows >> n, k (the input gradient of a per-point Linear): the streaming forward kernel on w^T
+    where it is built for the shape (the library GEMM takes ~160 us for 196608 x 64 @ 64 x 32 against ~30), the library otherwise."""
     be = backend()
     n, k = w.shape
     if a.is_cuda and hasattr(be, "linear_kernel_ok") and a.shape[0] >= 8192:
         a = a.contiguous()
         if be.linear_kernel_ok(a, k):
-            return be.linear(a, w.t().contiguous(), None, 1.0, None)
-    return a @ w
+            return be.linear(a, w.t().contiguous(), bias, 1.0, None)
+    return a @ w if bias is None else torch.addmm(bias, a, w)
 
 
 def _wgrad(gz, x):
@@ -333,17 +347,22 @@ class _Mlp2Fn(torch.autograd.Function):
         cout = w2.shape[0]
         x2 = x.reshape(-1, cin)
         gy = grad_out.reshape(-1, cout).contiguous()
-        hid = _tall_matmul(x2, w1.t())
-        if b1 is not None:
-            hid = hid + b1
-        pos = hid > 0
-        act = torch.where(pos, hid, hid * slope)
+        hid = _tall_matmul(x2, w1.t(), b1)
         g_act = _tall_matmul(gy, w2)                                   # (rows, hidden)
-        dw2, db2 = _wgrad(gy, act)
-        g_hid = torch.where(pos, g_act, g_act * slope)
         dslope = None
-        if ctx.slope_is_tensor and ctx.needs_input_grad[7]:
-            dslope = (g_act * torch.where(pos, torch.zeros_like(hid), hid)).sum().reshape(slope.shape)
+        if ctx.slope_is_tensor and hid.is_cuda:                        # the live PReLU slope: one pass each for act and (g_hid, dslope)
+            sl = slope.detach().reshape(1).contiguous()
+            hid, g_act = hid.contiguous(), g_act.contiguous()
+            act = _prelu_drop_fwd(hid, sl)
+            g_hid, dslope = _prelu_drop_bwd(hid, sl, g_act)
+            dslope = dslope.reshape(slope.shape) if ctx.needs_input_grad[7] else None
+        else:
+            pos = hid > 0
+            act = torch.where(pos, hid, hid * slope)
+            g_hid = torch.where(pos, g_act, g_act * slope)
+            if ctx.slope_is_tensor and ctx.needs_input_grad[7]:
+                dslope = (g_act * torch.where(pos, torch.zeros_like(hid), hid)).sum().reshape(slope.shape)
+        dw2, db2 = _wgrad(gy, act)
         dw1, db1 = _wgrad(g_hid, x2)
         dx = _tall_matmul(g_hid, w1).reshape(x.shape) if ctx.needs_input_grad[1] else None
         dres = grad_out if ctx.has_res and ctx.needs_input_grad[2] else None
@@ -372,7 +391,7 @@ class _LinearFn(torch.autograd.Function):
         n, k = w.shape
         gy = grad_out.reshape(-1, n)
         if ctx.slope != 1.0:
-            gz = torch.where(act.reshape(-1, n) > 0, gy, gy * ctx.slope)
+            gz = _leaky_grad(gy, act.reshape(-1, n), ctx.slope)
         else:
             gz = gy
         dx = dw = db = None
@@ -405,7 +424,7 @@ class _TorchLinearFn(torch.autograd.Function):
         x, w, act = ctx.saved_tensors
         n, k = w.shape
         gy = grad_out.reshape(-1, n)
-        gz = torch.where(act.reshape(-1, n) > 0, gy, gy * ctx.slope) if ctx.slope != 1.0 else gy
+        gz = _leaky_grad(gy, act.reshape(-1, n), ctx.slope) if ctx.slope != 1.0 else gy
         dx = _tall_matmul(gz, w).reshape(x.shape) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
