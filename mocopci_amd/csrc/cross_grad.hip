@@ -126,11 +126,57 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
     for (int t = 0; t < T; ++t) { dbp[t] = 0.f; dWp[t][0] = 0.f; dWp[t][1] = 0.f; dWp[t][2] = 0.f; }
     const uint32_t lower_lanes = (1u << col) - 1u;
 
+    // D = 64 (316 registers, one wave per SIMD: nothing hides a gather): the point's operands -- its neighbour rows, its own row, its
+    // output gradient, the coordinates -- are loaded one iteration AHEAD into 100 registers, the neighbour indices two ahead (the rows'
+    // addresses depend on them); round 5 counters: 43 % of this kernel's wave time was s_waitcnt.  D = 128 has no registers to spare.
+    constexpr bool PIPE = D == 64;
+    struct Pre {
+        float q[3], c[3];
+        float4 r1[4 * T], r2[4 * T], gr[4 * T];
+    };
+    auto load_id = [&](long long pp) -> int { return idx2 ? (col >= 16 ? idx2[pp * 16 + col - 16] : idx[pp * 16 + col]) : idx[pp * KNB + col]; };
+    auto fetch = [&](long long pp, int idn, Pre &o) {
+        const long long bn = mcp_div(pp, n1, mcp_fits32(total));
+        const float *q2n = xyz2 + ((long long)bn * n2 + idn) * 3;
+        const float4 *r2n = reinterpret_cast<const float4 *>(points2 + ((long long)bn * n2 + idn) * D);
+        const float4 *r1n = reinterpret_cast<const float4 *>(points1 + pp * D);
+        const float4 *grn = reinterpret_cast<const float4 *>(gout + pp * D);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o.q[k] = q2n[k]; o.c[k] = xyz1[pp * 3 + k]; }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int at = (32 * t + 8 * g + 4 * h) >> 2;
+                o.r1[4 * t + g] = r1n[at];
+                o.r2[4 * t + g] = r2n[at];
+                o.gr[4 * t + g] = grn[at];
+            }
+    };
+    Pre cur;
+    int id_ahead = 0;
+    if (PIPE) {
+        const long long p0 = first + wave;
+        if (p0 < total) {
+            fetch(p0, load_id(p0), cur);
+            if (p0 + step < total) id_ahead = load_id(p0 + step);
+        }
+    }
+
     for (long long p = first + wave; p < total; p += step) {
         const long long bb = mcp_div(p, n1, mcp_fits32(total));
-        const int id = idx2 ? (col >= 16 ? idx2[p * 16 + col - 16] : idx[p * 16 + col]) : idx[p * KNB + col];
+        Pre nxt;
+        int id_ahead2 = 0;
+        int id = 0;
+        if (PIPE) {
+            if (p + step < total) fetch(p + step, id_ahead, nxt);          // wave-uniform
+            if (p + 2 * step < total) id_ahead2 = load_id(p + 2 * step);
+        } else {
+            id = load_id(p);
+        }
         const float *q2 = xyz2 + ((long long)bb * n2 + id) * 3;
-        const float dx = q2[0] - xyz1[p * 3 + 0], dy = q2[1] - xyz1[p * 3 + 1], dzc = q2[2] - xyz1[p * 3 + 2];
+        const float dx = PIPE ? cur.q[0] - cur.c[0] : q2[0] - xyz1[p * 3 + 0], dy = PIPE ? cur.q[1] - cur.c[1] : q2[1] - xyz1[p * 3 + 1],
+                    dzc = PIPE ? cur.q[2] - cur.c[2] : q2[2] - xyz1[p * 3 + 2];
         const float in0 = h ? dy : dx, in1 = h ? 1.0f : dzc;
         const float4 *row2 = reinterpret_cast<const float4 *>(points2 + ((long long)bb * n2 + id) * D);
         const float4 *row1 = reinterpret_cast<const float4 *>(points1 + p * D);
@@ -146,8 +192,8 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
                 float4 rg[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 a = row1[(32 * t + 8 * g + 4 * h) >> 2];
-                    rg[g] = row2[(32 * t + 8 * g + 4 * h) >> 2];
+                    const float4 a = PIPE ? cur.r1[4 * t + g] : row1[(32 * t + 8 * g + 4 * h) >> 2];
+                    rg[g] = PIPE ? cur.r2[4 * t + g] : row2[(32 * t + 8 * g + 4 * h) >> 2];
                     acc[4 * g + 0] = a.x; acc[4 * g + 1] = a.y; acc[4 * g + 2] = a.z; acc[4 * g + 3] = a.w;
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[S::L_POS + (t * 2 + 0) * 64 + lane], in0, acc, 0, 0, 0);
@@ -184,7 +230,7 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
                 f32x16 dzt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 gv = grow[(32 * t + 8 * g + 4 * h) >> 2];
+                    const float4 gv = PIPE ? cur.gr[4 * t + g] : grow[(32 * t + 8 * g + 4 * h) >> 2];
                     const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -310,6 +356,10 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (PIPE) {
+            cur = nxt;
+            id_ahead = id_ahead2;
+        }
     }
 
     // ---- the workgroup's partial vector (zero where another role owns the entry): waves added in wave order through LDS ----

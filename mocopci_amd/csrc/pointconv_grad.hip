@@ -65,6 +65,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pointconv_agg_grad_kernel(long 
         const int id = idx[pc * K + k];
         const float *q = s_xyz + ((long long)bb * n + id) * 3;
         const float x0 = q[0] - new_xyz[pc * 3 + 0], x1 = q[1] - new_xyz[pc * 3 + 1], x2 = q[2] - new_xyz[pc * 3 + 2];
+        // every lane walks its own gathered row: with one wave per SIMD (176 accumulators per lane) nothing hides a load, and two loads
+        // in flight (the old unroll-by-2 loop) left 65 % of the wave's time in s_waitcnt (round 5 counters).  The row is read in chunks
+        // of CHUNK float4: the first chunk's loads are issued here, in front of the WeightNet arithmetic, every later chunk's while the
+        // one before it is used.
+        constexpr int CHUNK = 8;
+        const float4 *row = reinterpret_cast<const float4 *>(s_points + ((long long)bb * n + id) * d);
+        const int quads = d >> 2;
+        float4 cur[CHUNK], nxt[CHUNK];
+#pragma unroll
+        for (int i = 0; i < CHUNK; ++i) cur[i] = i < quads ? row[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         // ---- the WeightNet again (pointconv_agg_kernel's fma order) ----
         float h0[WN], h1[WN], h2[WN];
 #pragma unroll
@@ -100,17 +110,25 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pointconv_agg_grad_kernel(long 
         };
         float dg0 = channel(x0, 0), dg1 = channel(x1, 1), dg2 = channel(x2, 2);
         {
-            const float4 *row = reinterpret_cast<const float4 *>(s_points + ((long long)bb * n + id) * d);
             float4 *orow = reinterpret_cast<float4 *>(d_rows + (pc * K + k) * d);
-#pragma unroll 2
-            for (int c4 = 0; c4 < (d >> 2); ++c4) {
-                const float4 f = row[c4];
-                float4 o;
-                o.x = channel(f.x, 3 + 4 * c4 + 0);
-                o.y = channel(f.y, 3 + 4 * c4 + 1);
-                o.z = channel(f.z, 3 + 4 * c4 + 2);
-                o.w = channel(f.w, 3 + 4 * c4 + 3);
-                if (valid) orow[c4] = o;
+            for (int c0 = 0; c0 < quads; c0 += CHUNK) {
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) nxt[i] = c0 + CHUNK + i < quads ? row[c0 + CHUNK + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    const int c4 = c0 + i;
+                    if (c4 < quads) {   // wave-uniform
+                        const float4 f = cur[i];
+                        float4 o;
+                        o.x = channel(f.x, 3 + 4 * c4 + 0);
+                        o.y = channel(f.y, 3 + 4 * c4 + 1);
+                        o.z = channel(f.z, 3 + 4 * c4 + 2);
+                        o.w = channel(f.w, 3 + 4 * c4 + 3);
+                        if (valid) orow[c4] = o;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) cur[i] = nxt[i];
             }
         }
         // ---- back through the WeightNet ----

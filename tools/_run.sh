@@ -1,16 +1,9 @@
 set -e
-mkdir -p gpurun_out/r05e
-python bench.py > gpurun_out/r05e/bench.json 2> gpurun_out/r05e/bench.err
-echo bench done
-bash tools/profile_config.sh c4 r05e_c4 > gpurun_out/r05e/c4.log 2>&1
-python bench.py --config c4 > gpurun_out/r05e_c4/bench.json 2> gpurun_out/r05e_c4/bench.err
-echo c4 done
-bash tools/profile_config.sh c5 r05e_c5 > gpurun_out/r05e/c5.log 2>&1
-python bench.py --config c5 > gpurun_out/r05e_c5/bench.json 2> gpurun_out/r05e_c5/bench.err
-echo c5 done
-python bench.py --train-step eval > gpurun_out/r05e/train_step_eval.json 2> gpurun_out/r05e/train_eval.err
-python bench.py --train-step train > gpurun_out/r05e/train_step_train.json 2> gpurun_out/r05e/train_train.err
-echo train done
-python tools/schedule_waits.py > gpurun_out/r05e/schedule_waits.txt 2>&1
-python tools/ablate.py > gpurun_out/r05e/ablation.txt 2>&1
-echo all done
+mkdir -p gpurun_out/r5ap
+export TMPDIR=/tmp
+python -m pytest tests/test_grad_gpu.py -x -q > gpurun_out/r5ap/tests.txt 2>&1
+python tools/train_step_time.py 8 8192 train 10 > gpurun_out/r5ap/step_train.txt 2>&1
+python tools/train_step_time.py 8 8192 eval 10 > gpurun_out/r5ap/step_eval.txt 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/r5ap/trace -o train -- python tools/train_step_time.py 8 8192 eval > gpurun_out/r5ap/traced.txt 2>&1
+python tools/rocpd_top.py $(find gpurun_out/r5ap/trace -name '*.db' | head -1) 30 > gpurun_out/r5ap/top_eval.txt 2>&1
+rm -rf gpurun_out/r5ap/trace
