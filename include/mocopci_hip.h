@@ -215,6 +215,14 @@ int mcp_interp3_apply(int b, int n, int s, int c, const float *feat, const int *
 int mcp_interp3_apply_grad(int b, int n, int s, int c, const float *grad_out, const int *idx3, const float *w3, float *grad_feat,
                            mcp_stream_t stream);
 
+/* Deterministic backward of mcp_interp3_apply (autograd over the blend of UpsampleFlow / PointWarping, mocopci.py:1480-1481,
+ * :1500-1501; the reference's K9, interpolate_gpu.cu:120-161, adds with atomicAdd): grad_w3 (B,N,3) = <grad_out[b,p,:],
+ * feat[b, idx3[b,p,j], :]> and grad_feat (B,S,C) = the w3-weighted scatter of grad_out, every destination row's addends in ascending
+ * position 3p + j -- (order (B,3N), seg (B,S+1)) = mcp_scatter_segments of idx3 viewed as (B, 3N) with n = S.  Either output may be
+ * NULL (then feat / order / seg are not read).  Sums in a fixed order: bit-reproducible; no (B,N,3,C) intermediate. */
+int mcp_interp3_apply_grad_sorted(int b, int n, int s, int c, const float *feat, const int *idx3, const float *w3, const float *grad_out,
+                                  const int *order, const int *seg, float *grad_feat, float *grad_w3, mcp_stream_t stream);
+
 /* MultiFrameEstimatier.knn_group + fusion (mocopci.py:798-819) after the two neighbour searches:
  * p1 (B,N,3) centres, p2 (B,N,3) gathered set, idx (B,N,64) int32 into p2 (32 self-neighbours of p1
  * followed by 32 neighbours of p1 in p2); per neighbour [d, |d|] -> 4->64->64->128 (1x1 conv + eval

@@ -45,6 +45,7 @@ SIGNATURES = {
     "mcp_interp3_weights": [_i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_interp3_apply": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_interp3_apply_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "mcp_interp3_apply_grad_sorted": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "mcp_group_rows_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
     "mcp_group_rows_grad_sorted": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_group_rows_add_leaky": [_i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],

@@ -58,6 +58,33 @@ def _interp3_apply_fwd(feat, idx3, w3):
     return out
 
 
+class _Interp3ApplyFn(torch.autograd.Function):
+    """mcp_interp3_apply with its deterministic backward (mcp_interp3_apply_grad_sorted): the weights' gradient as a gather-dot, the
+    features' as a weighted segmented reduction over the CSR form of idx3 -- no (B,N,3,C) tensor (autograd over the unfused blend
+    builds three)."""
+
+    @staticmethod
+    def forward(ctx, feat, idx3, w3):
+        feat, idx3, w3 = feat.detach().contiguous(), idx3.contiguous(), w3.detach().contiguous()
+        ctx.save_for_backward(feat, idx3, w3)
+        return _interp3_apply_fwd(feat, idx3, w3)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feat, idx3, w3 = ctx.saved_tensors
+        B, N, _ = idx3.shape
+        S, C = feat.shape[1], feat.shape[2]
+        grad_out = grad_out.contiguous()
+        need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
+        d_feat = torch.empty_like(feat) if need_f else None
+        d_w3 = torch.empty_like(w3) if need_w else None
+        order, seg = _scatter_segments(idx3, S) if need_f else (None, None)
+        _call("mcp_interp3_apply_grad_sorted", feat, B, N, S, C, _lib.fptr(feat), _lib.iptr(idx3), _lib.fptr(w3), _lib.fptr(grad_out),
+              None if order is None else _lib.iptr(order), None if seg is None else _lib.iptr(seg),
+              None if d_feat is None else _lib.fptr(d_feat), None if d_w3 is None else _lib.fptr(d_w3))
+        return d_feat, None, d_w3
+
+
 class _GroupRowsFn(torch.autograd.Function):
     """Row gather with its scatter-add backward (channel-last counterpart of GroupingOperation, pointnet2_utils.py:156-198)."""
 
@@ -735,8 +762,14 @@ class HipBackend:
 
     def interp3_apply(self, feat, idx3, w3):
         """Blend of the three neighbours' rows; differentiable w.r.t. feat and the weights."""
-        return grad.run(lambda f, i, w: _interp3_apply_fwd(f.contiguous(), i.contiguous(), w.contiguous()),
-                        lambda f, i, w: grad.interp3_apply_twin(self.group_rows, f, i, w), feat, idx3, w3)
+        if grad.wants_grad(feat, w3):
+            if not self.EXPLICIT_INTERP3_GRAD:   # A/B switch: autograd over the unfused blend
+                return grad.run(lambda f, i, w: _interp3_apply_fwd(f.contiguous(), i.contiguous(), w.contiguous()),
+                                lambda f, i, w: grad.interp3_apply_twin(self.group_rows, f, i, w), feat, idx3, w3)
+            return _Interp3ApplyFn.apply(feat, idx3, w3)
+        return _interp3_apply_fwd(feat.contiguous(), idx3.contiguous(), w3.contiguous())
+
+    EXPLICIT_INTERP3_GRAD = True
 
     def interp3(self, dense, sparse, feat):
         """UpsampleFlow.forward (mocopci.py:1485-1502): dense (B,N,3), sparse (B,S,3), feat (B,S,C) -> (B,N,C)."""

@@ -1,7 +1,8 @@
 """-m gpu: gradients of the fused layers.  Forward in training is the fused HIP kernel; the backward of the fusion layer,
 the D = 64 / 128 cost volumes, the PointConv aggregation, the vector-attention block, the narrow-head attention, the per-point Linear and
 the two-layer MLP is a hand-written kernel (or a composition of the streaming kernels) with the deterministic segmented-reduction
-scatter; the remaining layers (cross D = 256, interp3, wide-head attention) differentiate their unfused twin (mocopci_amd/grad.py).
+scatter -- so is the 3-neighbour blend's (gather-dot + weighted segmented reduction); the remaining layers (cross D = 256, the interpolation
+weights, wide-head attention) differentiate their unfused twin (mocopci_amd/grad.py).
 Each layer's gradients -- w.r.t. coordinates, features and weights -- are compared with float64 re-derivations or with torch autograd on
 the CPU through the oracle backend's own restatement of the layer; one training iteration is compared with the gradients the REFERENCE
 computes through its own autograd.Functions (tests/golden/train_grad_b1_n1024.npz) and, end to end, with the oracle backend."""
@@ -478,6 +479,36 @@ def test_interp3_gradients_reach_features_and_coordinates(n, s, c):
     dense, sparse, feat = cloud(70, 2, n), cloud(71, 2, s), rnd(72, 2, s, c)
     ob, be = OracleBackend(), ops.backend()
     compare_grads(lambda a, b, f: be.interp3(a, b, f), lambda a, b, f: ob.interp3(a, b, f), [dense, sparse, feat], names=["dense", "sparse", "feat"])
+
+
+@pytest.mark.parametrize("n,s,c", [(500, 120, 3), (4096, 2048, 64), (900, 40, 35)])
+def test_interp3_blend_backward_kernels_match_float64_and_repeat(n, s, c):
+    """mcp_interp3_apply_grad_sorted (UpsampleFlow / PointWarping's blend, mocopci.py:1480-1481): both gradients against float64 autograd
+    over the unfused blend, the same bits on every call, and against the unfused twin's autograd on the device; either output alone."""
+    from mocopci_amd import grad as G
+    be = ops.backend()
+    gen = torch.Generator().manual_seed(n + c)
+    feat, w3, g = rnd(300, 2, s, c).to(DEV), torch.rand(2, n, 3, generator=gen).to(DEV), rnd(301, 2, n, c).to(DEV)
+    idx3 = torch.randint(0, s, (2, n, 3), generator=gen, dtype=torch.int32)
+    idx3[:, : n // 3] = idx3[:, : n // 3] % 2            # two rows that a third of the points blend from
+    idx3 = idx3.to(DEV)
+    leaves = [feat.clone().requires_grad_(True), w3.clone().requires_grad_(True)]
+    got = torch.autograd.grad(ops._Interp3ApplyFn.apply(leaves[0], idx3, leaves[1]), leaves, g)
+    again = torch.autograd.grad(ops._Interp3ApplyFn.apply(leaves[0], idx3, leaves[1]), leaves, g)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    l64 = [feat.double().clone().requires_grad_(True), w3.double().clone().requires_grad_(True)]
+    bidx = torch.arange(2, device=DEV).view(2, 1, 1)
+    want = torch.autograd.grad((l64[1].unsqueeze(-1) * l64[0][bidx, idx3.long()]).sum(2), l64, g.double())
+    for name, a, b in zip(("feat", "w3"), got, want):
+        scale = float(b.abs().max())
+        assert float((a.double() - b).abs().max()) <= 2e-6 * scale * max(1.0, (n / s) ** 0.5), name
+    tw = [feat.clone().requires_grad_(True), w3.clone().requires_grad_(True)]
+    twin = torch.autograd.grad(G.interp3_apply_twin(be.group_rows, tw[0], idx3, tw[1]), tw, g)
+    for a, b in zip(got, twin):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    only_w = torch.autograd.grad(ops._Interp3ApplyFn.apply(feat, idx3, leaves[1]), [leaves[1]], g)[0]
+    only_f = torch.autograd.grad(ops._Interp3ApplyFn.apply(leaves[0], idx3, w3), [leaves[0]], g)[0]
+    assert torch.equal(only_w, got[1]) and torch.equal(only_f, got[0])
 
 
 @pytest.mark.parametrize("cin,hidden,cout", [(64, 256, 64), (128, 512, 3)])  # both heads of the two levels
