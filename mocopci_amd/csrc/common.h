@@ -88,6 +88,28 @@ static inline int mcp_launch_status() {
 }
 static inline unsigned mcp_divup(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// Which units (points, point pairs) a workgroup of a persistent-style kernel takes.  The hardware deals workgroups to the chip's eight
+// XCDs round-robin (workgroup i -> XCD i mod 8) and every XCD has its own L2.  With units dealt round-robin too (unit = blockIdx * per_wg,
+// step gridDim * per_wg) every L2 sees the rows that every batch element's points gather; here XCD x takes the x-th eighth of the units
+// instead -- whole batch elements when the batch is a multiple of 8 -- so the rows its waves gather stay in ITS L2 (cross_kernel<64> at
+// 40 x 2048 points: FETCH_SIZE 104 -> 27 thousand units per launch, round 5).  A workgroup starts at `first`, advances by `stride`, stops
+// at `limit`; eighths are multiples of per_wg, so a workgroup's step never straddles two of them.  Grids that are not a multiple of 8
+// keep the round-robin deal.
+struct McpUnits {
+    long long first, limit, stride;
+};
+__device__ __forceinline__ McpUnits mcp_units_by_xcd(long long total, int per_wg) {
+#ifndef MCP_NO_XCD_MAP
+    if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
+        const long long steps = (total + per_wg - 1) / per_wg, chunk = ((steps + 7) / 8) * per_wg;
+        const long long x = blockIdx.x & 7;
+        const long long lim = (x + 1) * chunk;
+        return {x * chunk + (long long)(blockIdx.x >> 3) * per_wg, lim < total ? lim : total, (long long)(gridDim.x >> 3) * per_wg};
+    }
+#endif
+    return {(long long)blockIdx.x * per_wg, total, (long long)gridDim.x * per_wg};
+}
+
 // A pair of floats with element-wise arithmetic -- deliberately NOT an ext-vector type, and the library is built with
 // -fno-slp-vectorize -fno-vectorize: no packed-fp32 instruction (v_pk_add/mul/fma_f32) may be formed.  Cause, established in round 3
 // (tools/ab/): a v_pk_*_f32 result needs more wait states before its consumer than this compiler inserts.

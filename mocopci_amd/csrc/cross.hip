@@ -189,8 +189,19 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
     // formed where they are consumed), the batch map is read from LDS (a global lookup feeding an address would be a dependent
     // round trip in the middle of the issue sequence), and the points1 row -- the same 4 D bytes for all 32 neighbours -- is one
     // float4 per lane that goes through a wave-private LDS row into accumulator layout instead of 4 T broadcast loads per lane.
-    const long long stride = (long long)gridDim.x * WAVES;
-    long long p = (long long)blockIdx.x * WAVES + wave;
+    // Which points a workgroup takes.  The hardware deals workgroups to the eight XCDs round-robin (workgroup i -> XCD i mod 8), and
+    // every XCD has its own L2: with points dealt round-robin too, every L2 sees the gathered rows of every batch element.  Instead XCD x
+    // takes the x-th eighth of the points -- whole batch elements when the batch is a multiple of 8 --, so the rows its waves gather
+    // (points2 of 1-3 batch elements: 0.5-1.5 MB) stay in ITS L2.  `limit` replaces `total` in the loop below.
+#ifndef MCP_NO_XCD_MAP
+    const bool by_xcd = gridDim.x >= 8 && (gridDim.x & 7) == 0;
+#else
+    const bool by_xcd = false;
+#endif
+    const long long chunk = by_xcd ? (total + 7) / 8 : total;
+    const long long stride = (long long)(by_xcd ? gridDim.x >> 3 : gridDim.x) * WAVES;
+    const long long limit = by_xcd ? min(total, ((long long)(blockIdx.x & 7) + 1) * chunk) : total;
+    long long p = by_xcd ? (long long)(blockIdx.x & 7) * chunk + (long long)(blockIdx.x >> 3) * WAVES + wave : (long long)blockIdx.x * WAVES + wave;
     float q2x = 0.f, q2y = 0.f, q2z = 0.f, p1x = 0.f, p1y = 0.f, p1z = 0.f;  // raw coordinates of the point in flight
     float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);                               // float4 number `lane` of its points1 row (lane < D/4)
     float4 rg[T][4];                                                          // its gathered points2 row, accumulator layout
@@ -230,15 +241,15 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
     Pos qp{(int)(p / n1), (int)(p % n1)};
     Pos qn = advance(qp), qnn = advance(qn);
     int idn = 0;
-    if (p < total) {
+    if (p < limit) {
         fetch(p, qp, nbr(p, qp));
-        if (pn < total) idn = nbr(pn, qn);
+        if (pn < limit) idn = nbr(pn, qn);
     }
 #ifdef MCP_CROSS_DIAG
     unsigned long long t_prev = 0;
     CROSS_STAMP(7);
 #endif
-    for (; p < total; p = pn, pn += stride) {
+    for (; p < limit; p = pn, pn += stride) {
         CROSS_STAMP(0);  // loop overhead / previous store
         f32x16 x0[L::BF ? 1 : T];
         McpSplit3 xs[L::BF ? 2 * T : 1];
@@ -271,9 +282,9 @@ __global__ __launch_bounds__(64 * CrossShape<D>::NW, CrossShape<D>::WG_PER_CU) v
         }
         __builtin_amdgcn_wave_barrier();  // the row has been read: the next point's may be written over it
         CROSS_STAMP(1);  // x0 build: waits for the prefetched loads, pos MFMA, epilogue, split
-        if (pn < total) {
+        if (pn < limit) {
             fetch(pn, qn, idn);
-            if (pn + stride < total) idn = nbr(pn + stride, qnn);
+            if (pn + stride < limit) idn = nbr(pn + stride, qnn);
         }
         qn = qnn;
         qnn = advance(qnn);

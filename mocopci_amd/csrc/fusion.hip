@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_kernel(long long total, 
     const float4 *w2q = reinterpret_cast<const float4 *>(lds + OFF_W2);
     const float4 *w3q = reinterpret_cast<const float4 *>(lds + OFF_W3);
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
         const long long bb = mcp_div(p, n, mcp_fits32(total));
         const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
         float score[2], nbx[2], nby[2], nbz[2];
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_split_kernel(long long t
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
         const long long bb = mcp_div(p, n, mcp_fits32(total));
         const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
         float score[2], nbx[2], nby[2], nbz[2];

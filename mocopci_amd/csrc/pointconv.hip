@@ -41,7 +41,8 @@ __global__ __launch_bounds__(THREADS) void pointconv_agg_kernel(long long total,
     const bool f32 = mcp_fits32(total);
     const bool off32 = (long long)n * d < (1LL << 31);
     const int d4 = d >> 2;
-    for (long long p0 = (long long)blockIdx.x * PPB; p0 < total; p0 += (long long)gridDim.x * PPB) {
+    const McpUnits units = mcp_units_by_xcd(total, PPB);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p0 = units.first; p0 < units.limit; p0 += units.stride) {
         __syncthreads();
         // ---- phase 1: WeightNet 3 -> 8 -> 8 -> 8 per (point, neighbour) ----
         for (int pair = tid; pair < PPB * K; pair += THREADS) {
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(THREADS) void pointconv_agg_lowlevel_kernel(long lo
     const int cin = d + 3;
     const bool f32 = mcp_fits32(total);
     const bool off32 = (long long)n * d < (1LL << 31);
-    for (long long p0 = (long long)blockIdx.x * LPPB; p0 < total; p0 += (long long)gridDim.x * LPPB) {
+    const McpUnits units = mcp_units_by_xcd(total, LPPB);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p0 = units.first; p0 < units.limit; p0 += units.stride) {
         __syncthreads();
         {   // ---- phase 1 ----
             const int pl = tid >> 5, k = tid & 31;
@@ -292,7 +294,8 @@ __global__ __launch_bounds__(8 * D) __attribute__((amdgpu_waves_per_eu(D == 32 ?
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
     const bool f32 = mcp_fits32(total);
     const bool off32 = (long long)n * D < (1LL << 31);
-    for (long long p0 = (long long)blockIdx.x * FPPB; p0 < total; p0 += (long long)gridDim.x * FPPB) {
+    const McpUnits units = mcp_units_by_xcd(total, FPPB);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p0 = units.first; p0 < units.limit; p0 += units.stride) {
         __syncthreads();
         // ---- phase 1: WeightNet 3 -> 8 -> 8 -> 8 per (point, neighbour) ----
         for (int pair = tid; pair < FPPB * K; pair += THREADS) {

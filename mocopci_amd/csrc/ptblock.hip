@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ptblock_kernel(long long total,
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31, sel = col >> 4, j = col & 15;
     const long long pairs = (total + 1) / 2;
-    for (long long pp = (long long)blockIdx.x * WAVES + wave; pp < pairs; pp += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(pairs, WAVES);   // XCD x takes the x-th eighth of the point pairs (common.h)
+    for (long long pp = units.first + wave; pp < units.limit; pp += units.stride) {
         long long p = 2 * pp + sel;
         const bool live = p < total;
         if (!live) p = total - 1;  // odd tail: the second half of the wave recomputes the last point and does not store
