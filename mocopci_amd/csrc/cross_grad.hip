@@ -75,10 +75,11 @@ __global__ __launch_bounds__(256) void transposed_image_kernel(uint4 *dst, const
     mcp_split_weights_transposed(dst, w, d, d, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-// One workgroup of a role: points first, first + step, ... of the launch.  DATA: dx, the per-neighbour outputs, dWpos;
+// One workgroup of a role: points first, first + step, ... below limit.  DATA: dx, the per-neighbour outputs, dWpos;
 // OWN >= 0: rows 32 OWN .. 32 OWN + 63 of dWmlp (and of dbmlp).
 template <int D, bool DATA, int OWN>
-__device__ __forceinline__ void cross_grad_body(float *lds, long long total, int n1, int n2, long long first, long long step, const float *__restrict__ xyz1,
+__device__ __forceinline__ void cross_grad_body(float *lds, long long total, int n1, int n2, long long first, long long step, long long limit,
+                                                const float *__restrict__ xyz1,
                                                 const float *__restrict__ xyz2, const float *__restrict__ points1, const float *__restrict__ points2,
                                                 const int *__restrict__ idx, const int *__restrict__ idx2, const float *__restrict__ wpos,
                                                 const float *__restrict__ bpos, const float *__restrict__ wmlp, const float *__restrict__ bmlp,
@@ -157,20 +158,20 @@ __device__ __forceinline__ void cross_grad_body(float *lds, long long total, int
     int id_ahead = 0;
     if (PIPE) {
         const long long p0 = first + wave;
-        if (p0 < total) {
+        if (p0 < limit) {
             fetch(p0, load_id(p0), cur);
-            if (p0 + step < total) id_ahead = load_id(p0 + step);
+            if (p0 + step < limit) id_ahead = load_id(p0 + step);
         }
     }
 
-    for (long long p = first + wave; p < total; p += step) {
+    for (long long p = first + wave; p < limit; p += step) {
         const long long bb = mcp_div(p, n1, mcp_fits32(total));
         Pre nxt;
         int id_ahead2 = 0;
         int id = 0;
         if (PIPE) {
-            if (p + step < total) fetch(p + step, id_ahead, nxt);          // wave-uniform
-            if (p + 2 * step < total) id_ahead2 = load_id(p + 2 * step);
+            if (p + step < limit) fetch(p + step, id_ahead, nxt);          // wave-uniform
+            if (p + 2 * step < limit) id_ahead2 = load_id(p + 2 * step);
         } else {
             id = load_id(p);
         }
@@ -412,15 +413,33 @@ __global__ __launch_bounds__(64 * GradShape<D>::WAVES, 1) void cross_grad_kernel
     float *prow = partial + (size_t)blockIdx.x * S::G_FLOATS;
     const int bx = (int)blockIdx.x;
 #define MCP_CROSS_GRAD_ARGS xyz1, xyz2, points1, points2, idx, idx2, wpos, bpos, wmlp, bmlp, wt_global, gout, d_xyz1, d_dir, d_points1, d_rows, prow
+    // the points of workgroup k of a role with g workgroups that starts at workgroup `base` of the launch: XCD x (= blockIdx mod 8) takes
+    // the x-th eighth of the points when the role's workgroups are spread evenly over the XCDs (common.h: mcp_units_by_xcd), else round-robin
+    long long first, step, limit = total;
+    auto deal = [&](int k, int g, int base) {
+        first = (long long)k * S::WAVES;
+        step = (long long)g * S::WAVES;
+#ifndef MCP_NO_XCD_MAP
+        if (g >= 8 && (g & 7) == 0 && (base & 7) == 0) {
+            const long long steps = (total + S::WAVES - 1) / S::WAVES, chunk = ((steps + 7) / 8) * S::WAVES, x = k & 7;
+            first = x * chunk + (long long)(k >> 3) * S::WAVES;
+            step = (long long)(g >> 3) * S::WAVES;
+            limit = (x + 1) * chunk < total ? (x + 1) * chunk : total;
+        }
+#endif
+    };
     if (S::ROLES == 1) {
-        cross_grad_body<D, true, 0>(lds, total, n1, n2, (long long)bx * S::WAVES, (long long)g0 * S::WAVES, MCP_CROSS_GRAD_ARGS);
+        deal(bx, g0, 0);
+        cross_grad_body<D, true, 0>(lds, total, n1, n2, first, step, limit, MCP_CROSS_GRAD_ARGS);
     } else if (bx < g0) {
-        cross_grad_body<D, true, -1>(lds, total, n1, n2, (long long)bx * S::WAVES, (long long)g0 * S::WAVES, MCP_CROSS_GRAD_ARGS);
+        deal(bx, g0, 0);
+        cross_grad_body<D, true, -1>(lds, total, n1, n2, first, step, limit, MCP_CROSS_GRAD_ARGS);
     } else if (bx < g0 + g1) {
-        cross_grad_body<D, false, 0>(lds, total, n1, n2, (long long)(bx - g0) * S::WAVES, (long long)g1 * S::WAVES, MCP_CROSS_GRAD_ARGS);
+        deal(bx - g0, g1, g0);
+        cross_grad_body<D, false, 0>(lds, total, n1, n2, first, step, limit, MCP_CROSS_GRAD_ARGS);
     } else {
-        cross_grad_body<D, false, (S::ROLES > 1 ? 2 : 0)>(lds, total, n1, n2, (long long)(bx - g0 - g1) * S::WAVES,
-                                                          (long long)((int)gridDim.x - g0 - g1) * S::WAVES, MCP_CROSS_GRAD_ARGS);
+        deal(bx - g0 - g1, (int)gridDim.x - g0 - g1, g0 + g1);
+        cross_grad_body<D, false, (S::ROLES > 1 ? 2 : 0)>(lds, total, n1, n2, first, step, limit, MCP_CROSS_GRAD_ARGS);
     }
 #undef MCP_CROSS_GRAD_ARGS
 }

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_fwd_kernel(long long 
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
         const long long bb = mcp_div(p, n, mcp_fits32(total));
         const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
         float score[2], nbx[2], nby[2], nbz[2];
@@ -388,7 +389,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b1_kernel(long long t
     float *dzb = scr + 32, *ezb = scr + 64;
     float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};  // lane = channel 32 mt + col
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
         const long long bb = mcp_div(p, n, mcp_fits32(total));
         const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
         const float gx = gout[p * 3 + 0], gy = gout[p * 3 + 1], gz = gout[p * 3 + 2];
@@ -548,7 +550,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b2_kernel(long long t
             for (int r = 0; r < 16; ++r) dW3a[a][b][r] = 0.f;
     float s2[2] = {0.f, 0.f}, g2[2] = {0.f, 0.f};
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
         const long long bb = mcp_div(p, n, mcp_fits32(total));
         const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
 #pragma unroll 1
@@ -727,7 +730,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_bn_b3_kernel(long long t
             for (int r = 0; r < 16; ++r) dW2a[a][b][r] = 0.f;
     float s1[2] = {0.f, 0.f}, g1[2] = {0.f, 0.f};
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
         const long long bb = mcp_div(p, n, mcp_fits32(total));
         const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
 #pragma unroll 1
@@ -865,7 +869,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b4_kernel(long long t
     float4 *x0b = reinterpret_cast<float4 *>(tb + 64 * TS);
     float dW1a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
         const long long bb = mcp_div(p, n, mcp_fits32(total));
         const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
         const float gx = gout[p * 3 + 0], gy = gout[p * 3 + 1], gz = gout[p * 3 + 2];

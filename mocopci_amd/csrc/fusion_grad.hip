@@ -109,7 +109,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void fusion_grad_kernel(long long to
     // in-lane sums over transposed operands: lane = channel 32 mt + col, the two lane halves hold the two 8-neighbour groups
     float db1a[2] = {0.f, 0.f}, db2a[2] = {0.f, 0.f}, db3a[4] = {0.f, 0.f, 0.f, 0.f}, dW1a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
-    for (long long p = (long long)blockIdx.x * WAVES + wave; p < total; p += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // XCD x takes the x-th eighth of the points (common.h)
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
         const long long bb = mcp_div(p, n, mcp_fits32(total));
         const float cx = p1[p * 3 + 0], cy = p1[p * 3 + 1], cz = p1[p * 3 + 2];
         const float gx = gout[p * 3 + 0], gy = gout[p * 3 + 1], gz = gout[p * 3 + 2];

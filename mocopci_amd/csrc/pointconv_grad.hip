@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pointconv_agg_grad_kernel(long 
     for (int e = 0; e < G_FLOATS; ++e) acc[e] = 0.f;
 
     const long long pairs = (total + 1) >> 1;
-    for (long long it = (long long)blockIdx.x * WAVES + wave; it < pairs; it += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(pairs, WAVES);   // XCD x takes the x-th eighth of the centre pairs (common.h)
+    for (long long it = units.first + wave; it < units.limit; it += units.stride) {
         const long long p = 2 * it + pl;
         const bool valid = p < total;
         const long long pc = valid ? p : total - 1;  // a lane without a centre works on the last one with a zero gradient

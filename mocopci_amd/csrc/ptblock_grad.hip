@@ -145,7 +145,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void ptblock_grad_kernel(long long t
     float dWd1a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 
     const long long pairs = (total + 1) / 2;
-    for (long long pp = (long long)blockIdx.x * WAVES + wave; pp < pairs; pp += (long long)gridDim.x * WAVES) {
+    const McpUnits units = mcp_units_by_xcd(pairs, WAVES);   // XCD x takes the x-th eighth of the point pairs (common.h)
+    for (long long pp = units.first + wave; pp < units.limit; pp += units.stride) {
         long long p = 2 * pp + sel;
         const bool live = p < total;
         if (!live) p = total - 1;  // odd tail: the second half works on the last point with a zero upstream gradient
