@@ -380,6 +380,12 @@ int mcp_attention(int bf, int nq, int nk, int heads, int hd, const float *q, int
 int mcp_attention_small_dropout(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
                                 int v_stride, float scale, float drop_p, unsigned seed, float *out, mcp_stream_t stream);
 
+/* The same forward that also writes the rows' log-sum-exp (log2 domain; lse (BF, heads, Nq) floats) for mcp_attention_small_grad_lse: a
+ * training forward keeps it and the backward skips the statistics pass (the Q K^T products and exponentials of the whole score matrix a
+ * second time).  drop_p = 0: no mask, the result of mcp_attention_small bit for bit. */
+int mcp_attention_small_lse(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
+                            int v_stride, float scale, float drop_p, unsigned seed, float *out, float *lse, mcp_stream_t stream);
+
 /* Backward of mcp_attention_small / mcp_attention_small_dropout (head_dim 8 / 16; the reference differentiates the materialised
  * softmax of mocopci.py:72-86, :650-667 with autograd).  q, k, v, strides, scale as the forward (no key / value batch shift);
  * drop_p, seed as the forward's (0: no dropout); out (BF,Nq,heads*hd) the forward's output, grad_out its gradient, both dense.
@@ -390,6 +396,11 @@ size_t mcp_attention_small_grad_workspace_bytes(int bf, int nq, int heads);
 int mcp_attention_small_grad(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
                              int v_stride, float scale, float drop_p, unsigned seed, const float *out, const float *grad_out, float *grad_q,
                              float *grad_kv, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+/* mcp_attention_small_grad with the log-sum-exp the forward kept (mcp_attention_small_lse): one elementwise pass for D = dO . O, then the
+ * dQ and dK / dV kernels.  Same workspace size. */
+int mcp_attention_small_grad_lse(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
+                                 int v_stride, float scale, float drop_p, unsigned seed, const float *out, const float *grad_out, const float *lse,
+                                 float *grad_q, float *grad_kv, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
 
 /* Row normalisation with the additions in front of it (nn.LayerNorm semantics: biased variance, eps inside the root):
  *     z = x[r] (+ y[r]) (+ bias);   out[r] = (z - mean z) * rsqrt(var z + eps) (* gamma + beta)

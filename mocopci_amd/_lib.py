@@ -74,6 +74,8 @@ SIGNATURES = {
     "mcp_attention_small_grad_workspace_bytes": [_i, _i, _i],
     "mcp_attention_small_dropout": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _f, ctypes.c_uint, _p, _p],
     "mcp_attention_small_grad": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _f, ctypes.c_uint, _p, _p, _p, _p, _p, ctypes.c_size_t, _p],
+    "mcp_attention_small_lse": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _f, ctypes.c_uint, _p, _p, _p],
+    "mcp_attention_small_grad_lse": [_i] * 5 + [_p, _i, _p, _i, _p, _i, _f, _f, ctypes.c_uint, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p],
     "mcp_chamfer_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
     "mcp_ptblock_packed_floats": [],
     "mcp_ptblock_pack": [_p] * 10,

@@ -47,11 +47,13 @@ __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t row, uint32_
 
 // ---- the forward with dropout: mcp_attention_small's kernel (attention.hip) with the mask applied to P in P.V only (the row sums
 // that normalise the softmax are taken before the mask, as softmax -> dropout -> matmul does) ----
-template <int HD>
+// lse != NULL: the row's log-sum-exp (log2 domain, the statistic attention_stats_kernel recomputes) is written for the backward --
+// a training forward keeps it (mcp_attention_small_lse) and the backward skips the statistics pass.  DROP = false: no mask.
+template <int HD, bool DROP>
 __global__ __launch_bounds__(64 * WAVES) void attention_small_drop_kernel(int nq, int nk, int heads, const float *__restrict__ q, int qs,
                                                                           const float *__restrict__ k, int ks, const float *__restrict__ v, int vs,
                                                                           float scale_log2e, uint32_t seed, uint32_t threshold, float inv_keep,
-                                                                          float *__restrict__ out) {
+                                                                          float *__restrict__ out, float *__restrict__ lse) {
     constexpr int KS = HD + 1;
     __shared__ float kt[2][KT * KS];
     __shared__ __attribute__((aligned(16))) float vt[2][KT * HD];
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_drop_kernel(int nq
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(acc[r] - mn);
                 l += p;
-                float pm = p * drop_scale(seed, row, (uint32_t)(kbase + chan_of(r, h)), threshold, inv_keep);
+                float pm = DROP ? p * drop_scale(seed, row, (uint32_t)(kbase + chan_of(r, h)), threshold, inv_keep) : p;
                 int off = (sub * 32 + chan_of(r, h)) * HD;
                 asm volatile("" : "+v"(off), "+v"(pm));
                 const float *vr = &vt[cur][off];
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_drop_kernel(int nq
     const float mo = __shfl_xor(m, 32), lo = __shfl_xor(l, 32);
     const float mm = fmaxf(m, mo);
     const float a0 = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mm), a1 = mo == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mo - mm);
-    const float inv = 1.0f / (l * a0 + lo * a1);
+    const float lsum = l * a0 + lo * a1;
+    const float inv = 1.0f / lsum;
     float res[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) res[d] = (o[d] * a0 + __shfl_xor(o[d], 32) * a1) * inv;
@@ -160,7 +163,29 @@ __global__ __launch_bounds__(64 * WAVES) void attention_small_drop_kernel(int nq
         float *dst = out + qrow * (size_t)(heads * HD) + head * HD;
 #pragma unroll
         for (int d = 0; d < HD; d += 4) *reinterpret_cast<float4 *>(dst + d) = make_float4(res[d], res[d + 1], res[d + 2], res[d + 3]);
+        if (lse) lse[((size_t)bf * heads + head) * nq + qi] = mm + __builtin_amdgcn_logf(lsum);  // v_log_f32 is log2: as attention_stats_kernel
     }
+}
+
+// D = dO . O per (batch, head, query): what is left of the statistics pass when the forward kept the log-sum-exp
+template <int HD>
+__global__ __launch_bounds__(256) void attention_dsum_kernel(long long rows, int heads, const float *__restrict__ out, const float *__restrict__ gout,
+                                                            int nq, float *__restrict__ dsum) {
+    // thread = (batch, query, head) in the memory order of out / gout; dsum is (batch, head, query)
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows) return;
+    const float4 *o = reinterpret_cast<const float4 *>(out + e * HD), *g = reinterpret_cast<const float4 *>(gout + e * HD);
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+        const float4 a = g[c], b = o[c];
+        d = __builtin_fmaf(a.x, b.x, d); d = __builtin_fmaf(a.y, b.y, d); d = __builtin_fmaf(a.z, b.z, d); d = __builtin_fmaf(a.w, b.w, d);
+    }
+    const long long bq = e / heads;
+    const int head = (int)(e - bq * heads);
+    const long long bfi = bq / nq;
+    const int qi = (int)(bq - bfi * nq);
+    dsum[(bfi * heads + head) * nq + qi] = d;
 }
 
 // ---- stats: L (log2 domain) and D = dO . O per (batch, head, query) ----
@@ -485,12 +510,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attention_dkv_kernel(int nq, in
     }
 }
 
+// saved_lse != NULL: the forward's log-sum-exp (mcp_attention_small_lse): only D = dO . O is computed here; else the statistics pass
 template <int HD, bool DROP>
 int launch_all(int bf, int nq, int nk, int heads, const float *q, int qs, const float *k, int ks, const float *v, int vs, float scale, uint32_t seed,
-               uint32_t threshold, float inv_keep, const float *out, const float *gout, float *dq, float *dkv, float *lse, float *dsum, hipStream_t s) {
+               uint32_t threshold, float inv_keep, const float *out, const float *gout, float *dq, float *dkv, float *lse, float *dsum,
+               const float *saved_lse, hipStream_t s) {
     const float sl2 = scale * 1.44269504088896340736f;
     const dim3 gq(mcp_divup(nq, 32 * WAVES), heads, bf), gk(mcp_divup(nk, 32 * WAVES), heads, bf);
-    hipLaunchKernelGGL(attention_stats_kernel<HD>, gq, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, sl2, out, gout, lse, dsum);
+    if (saved_lse) {
+        const long long rows = (long long)bf * nq * heads;
+        hipLaunchKernelGGL(attention_dsum_kernel<HD>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, rows, heads, out, gout, nq, dsum);
+        lse = const_cast<float *>(saved_lse);   // read only below
+    } else {
+        hipLaunchKernelGGL(attention_stats_kernel<HD>, gq, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, sl2, out, gout, lse, dsum);
+    }
     hipLaunchKernelGGL((attention_dq_kernel<HD, DROP>), gq, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, v, vs, sl2, scale, seed, threshold, inv_keep,
                        gout, lse, dsum, dq);
     hipLaunchKernelGGL((attention_dkv_kernel<HD, DROP>), gk, dim3(64 * WAVES), 0, s, nq, nk, heads, q, qs, k, ks, v, vs, sl2, scale, seed, threshold, inv_keep,
@@ -513,8 +546,26 @@ MCP_EXPORT size_t mcp_attention_small_grad_workspace_bytes(int bf, int nq, int h
     return (size_t)2 * bf * heads * nq * sizeof(float);
 }
 
+namespace {
+int forward_with(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v, int v_stride,
+                 float scale, float drop_p, unsigned seed, float *out, float *lse, mcp_stream_t stream);
+}
+
 MCP_EXPORT int mcp_attention_small_dropout(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
                                            const float *v, int v_stride, float scale, float drop_p, unsigned seed, float *out, mcp_stream_t stream) {
+    return forward_with(bf, nq, nk, heads, hd, q, q_stride, k, k_stride, v, v_stride, scale, drop_p, seed, out, nullptr, stream);
+}
+
+MCP_EXPORT int mcp_attention_small_lse(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
+                                       const float *v, int v_stride, float scale, float drop_p, unsigned seed, float *out, float *lse,
+                                       mcp_stream_t stream) {
+    MCP_CHECK_ARGS(lse);
+    return forward_with(bf, nq, nk, heads, hd, q, q_stride, k, k_stride, v, v_stride, scale, drop_p, seed, out, lse, stream);
+}
+
+namespace {
+int forward_with(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v, int v_stride,
+                 float scale, float drop_p, unsigned seed, float *out, float *lse, mcp_stream_t stream) {
     MCP_CHECK_ARGS(bf > 0 && nq > 0 && nk > 0 && heads > 0 && q && k && v && out);
     if (hd != 8 && hd != 16) return MCP_ERR_UNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return MCP_ERR_BAD_ARG;
@@ -526,19 +577,45 @@ MCP_EXPORT int mcp_attention_small_dropout(int bf, int nq, int nk, int heads, in
     const float sl2 = scale * 1.44269504088896340736f;
     const dim3 grid(mcp_divup(nq, 32 * WAVES), heads, bf);
     mcp_prof_begin(MCP_KERNEL_ATTENTION, s);
-    if (hd == 8)
-        hipLaunchKernelGGL(attention_small_drop_kernel<8>, grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, seed, threshold,
-                           inv_keep, out);
-    else
-        hipLaunchKernelGGL(attention_small_drop_kernel<16>, grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, seed, threshold,
-                           inv_keep, out);
+#define MCP_ATT_FWD(HD_, DROP_)                                                                                                                     \
+    hipLaunchKernelGGL((attention_small_drop_kernel<HD_, DROP_>), grid, dim3(64 * WAVES), 0, s, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, sl2, \
+                       seed, threshold, inv_keep, out, lse)
+    if (drop_p > 0.f) {
+        if (hd == 8) MCP_ATT_FWD(8, true); else MCP_ATT_FWD(16, true);
+    } else {
+        if (hd == 8) MCP_ATT_FWD(8, false); else MCP_ATT_FWD(16, false);
+    }
+#undef MCP_ATT_FWD
     mcp_prof_end(MCP_KERNEL_ATTENTION, s);
     return mcp_launch_status();
+}
+}  // namespace
+
+namespace {
+int grad_with(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v, int v_stride, float scale,
+              float drop_p, unsigned seed, const float *out, const float *grad_out, const float *saved_lse, float *grad_q, float *grad_kv, void *workspace,
+              size_t workspace_bytes, mcp_stream_t stream);
 }
 
 MCP_EXPORT int mcp_attention_small_grad(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v,
                                         int v_stride, float scale, float drop_p, unsigned seed, const float *out, const float *grad_out, float *grad_q,
                                         float *grad_kv, void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
+    return grad_with(bf, nq, nk, heads, hd, q, q_stride, k, k_stride, v, v_stride, scale, drop_p, seed, out, grad_out, nullptr, grad_q, grad_kv, workspace,
+                     workspace_bytes, stream);
+}
+
+MCP_EXPORT int mcp_attention_small_grad_lse(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride,
+                                            const float *v, int v_stride, float scale, float drop_p, unsigned seed, const float *out, const float *grad_out,
+                                            const float *lse, float *grad_q, float *grad_kv, void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(lse);
+    return grad_with(bf, nq, nk, heads, hd, q, q_stride, k, k_stride, v, v_stride, scale, drop_p, seed, out, grad_out, lse, grad_q, grad_kv, workspace,
+                     workspace_bytes, stream);
+}
+
+namespace {
+int grad_with(int bf, int nq, int nk, int heads, int hd, const float *q, int q_stride, const float *k, int k_stride, const float *v, int v_stride, float scale,
+              float drop_p, unsigned seed, const float *out, const float *grad_out, const float *saved_lse, float *grad_q, float *grad_kv, void *workspace,
+              size_t workspace_bytes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(bf > 0 && nq > 0 && nk > 0 && heads > 0 && q && k && v && out && grad_out && grad_q && grad_kv && workspace);
     if (hd != 8 && hd != 16) return MCP_ERR_UNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)grad_out | (uintptr_t)grad_q | (uintptr_t)grad_kv) & 15) return MCP_ERR_BAD_ARG;
@@ -551,10 +628,11 @@ MCP_EXPORT int mcp_attention_small_grad(int bf, int nq, int nk, int heads, int h
     float *lse = static_cast<float *>(workspace), *dsum = lse + (size_t)bf * heads * nq;
     mcp_prof_begin(MCP_KERNEL_ATTENTION, s);
     int rc;
-#define MCP_ATT_ARGS bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, scale, seed, threshold, inv_keep, out, grad_out, grad_q, grad_kv, lse, dsum, s
+#define MCP_ATT_ARGS bf, nq, nk, heads, q, q_stride, k, k_stride, v, v_stride, scale, seed, threshold, inv_keep, out, grad_out, grad_q, grad_kv, lse, dsum, saved_lse, s
     if (drop_p > 0.f) rc = hd == 8 ? launch_all<8, true>(MCP_ATT_ARGS) : launch_all<16, true>(MCP_ATT_ARGS);
     else rc = hd == 8 ? launch_all<8, false>(MCP_ATT_ARGS) : launch_all<16, false>(MCP_ATT_ARGS);
 #undef MCP_ATT_ARGS
     mcp_prof_end(MCP_KERNEL_ATTENTION, s);
     return rc;
 }
+}  // namespace

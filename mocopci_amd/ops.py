@@ -256,14 +256,19 @@ class _AttentionSmallFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, be, q, kv, heads, scale, drop_p, seed):
         q, kv = q.detach().contiguous(), kv.detach().contiguous()
-        out = be._attention(q, kv, heads, scale, drop_p, seed)
+        BF, Nq, C = q.shape
+        Nk = kv.shape[1]
+        out = torch.empty((BF, Nq, C), dtype=torch.float32, device=q.device)
+        lse = torch.empty((BF, heads, Nq), dtype=torch.float32, device=q.device)   # kept for the backward: no statistics pass there
+        _call("mcp_attention_small_lse", q, BF, Nq, Nk, heads, C // heads, _lib.fptr(q), C, _lib.fptr(kv), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
+              float(scale), float(drop_p), int(seed), out.data_ptr(), lse.data_ptr())
         ctx.heads, ctx.scale, ctx.drop_p, ctx.seed = heads, scale, drop_p, seed
-        ctx.save_for_backward(q, kv, out)
+        ctx.save_for_backward(q, kv, out, lse)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        q, kv, out = ctx.saved_tensors
+        q, kv, out, lse = ctx.saved_tensors
         BF, Nq, C = q.shape
         Nk, heads = kv.shape[1], ctx.heads
         lib = _lib.load()
@@ -271,8 +276,9 @@ class _AttentionSmallFn(torch.autograd.Function):
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         need = lib.mcp_attention_small_grad_workspace_bytes(BF, Nq, heads)
         ws = torch.empty((need,), dtype=torch.uint8, device=q.device)
-        _call("mcp_attention_small_grad", q, BF, Nq, Nk, heads, C // heads, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
-              float(ctx.scale), float(ctx.drop_p), int(ctx.seed), _lib.fptr(out), _lib.fptr(grad_out), _lib.fptr(dq), _lib.fptr(dkv), ws.data_ptr(), need)
+        _call("mcp_attention_small_grad_lse", q, BF, Nq, Nk, heads, C // heads, q.data_ptr(), C, kv.data_ptr(), 2 * C, kv.data_ptr() + 4 * C, 2 * C,
+              float(ctx.scale), float(ctx.drop_p), int(ctx.seed), _lib.fptr(out), _lib.fptr(grad_out), _lib.fptr(lse), _lib.fptr(dq), _lib.fptr(dkv),
+              ws.data_ptr(), need)
         return None, dq, dkv, None, None, None, None
 
 

@@ -414,6 +414,45 @@ def test_prelu_dropout_kernels_match_torch_under_the_same_mask(shape):
     assert torch.equal(ops._PreluDropFn.apply(z, slope, 0.0, 1), torch.where(z > 0, z, slope * z))   # p = 0: plain PReLU
 
 
+@pytest.mark.parametrize("hd,nq,nk", [(8, 301, 450), (16, 128, 77), (8, 2048, 2048)])
+def test_attention_forward_that_keeps_the_log_sum_exp(hd, nq, nk):
+    """mcp_attention_small_lse (the training forward): at drop_p = 0 the output of mcp_attention_small bit for bit; its log-sum-exp is the
+    statistics pass's (mcp_attention_small_grad recomputes it) -- the two backward entry points return the same gradients bit for bit,
+    with and without dropout; lse against float64."""
+    import ctypes
+    from mocopci_amd import _lib
+    lib, be = _lib.load(), ops.backend()
+    bf, heads = 2, 8
+    C = heads * hd
+    q, kv, g = rnd(500, bf, nq, C).to(DEV), rnd(501, bf, nk, 2 * C).to(DEV), rnd(502, bf, nq, C).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    Pk, Pv = ctypes.c_void_p(kv.data_ptr()), ctypes.c_void_p(kv.data_ptr() + 4 * C)
+    scale = hd ** -0.5
+    for p_drop, seed in ((0.0, 0), (0.25, 4242)):
+        out, lse = torch.empty_like(q), torch.empty(bf, heads, nq, device=DEV)
+        assert lib.mcp_attention_small_lse(bf, nq, nk, heads, hd, P(q), C, Pk, 2 * C, Pv, 2 * C, scale, p_drop, seed, P(out), P(lse), st) == 0
+        if p_drop == 0.0:
+            assert torch.equal(out, be._attention(q, kv, heads, scale))
+            qh = q.double().reshape(bf, nq, heads, hd).permute(0, 2, 1, 3)
+            kh = kv.double().reshape(bf, nk, 2, heads, hd)[:, :, 0].permute(0, 2, 1, 3)
+            want = torch.logsumexp(qh @ kh.transpose(-2, -1) * scale, dim=-1) / 0.6931471805599453      # log2 domain
+            torch.testing.assert_close(lse.double(), want, rtol=1e-5, atol=1e-5)
+        else:
+            ref = torch.empty_like(q)
+            assert lib.mcp_attention_small_dropout(bf, nq, nk, heads, hd, P(q), C, Pk, 2 * C, Pv, 2 * C, scale, p_drop, seed, P(ref), st) == 0
+            assert torch.equal(out, ref)
+        need = lib.mcp_attention_small_grad_workspace_bytes(bf, nq, heads)
+        ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+        dq1, dkv1, dq2, dkv2 = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(q), torch.empty_like(kv)
+        assert lib.mcp_attention_small_grad(bf, nq, nk, heads, hd, P(q), C, Pk, 2 * C, Pv, 2 * C, scale, p_drop, seed, P(out), P(g), P(dq1), P(dkv1), P(ws), need, st) == 0
+        torch.cuda.synchronize()
+        assert lib.mcp_attention_small_grad_lse(bf, nq, nk, heads, hd, P(q), C, Pk, 2 * C, Pv, 2 * C, scale, p_drop, seed, P(out), P(g), P(lse), P(dq2), P(dkv2),
+                                                P(ws), need, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dq1, dq2) and torch.equal(dkv1, dkv2), p_drop
+
+
 def test_ptblock_backward_kernel_matches_the_unfused_block_and_repeats_bit_for_bit():
     """mcp_ptblock_grad against autograd over the unfused block (grad.ptblock_twin) on the device: q, k, v as slices of one packed
     projection (row stride 192), an odd point count (the last wave holds one point); two runs give identical bits.  Points with a
