@@ -1214,10 +1214,13 @@ class MoCoPCI(nn.Module):
         if train:
             # all six upsampled level-1 flows (mocopci.py:1011-1019): up_f[i] = upsample(frame1s_f[:, i]) on frame 1's points,
             # up_b[i] = upsample(frame1s_b[:, 2 - i]) on frame 2's points
-            src6 = torch.cat([frame1s[:B, 0], frame1s[:B, 1], frame1s[:B, 2], frame1s[B:, 2], frame1s[B:, 1], frame1s[B:, 0]], dim=0)
+            # (unbind, not six slices: its backward is one stack, a slice's is a zero-filled tensor plus a copy)
+            lv1 = [d.unbind(1) for d in frame1s.reshape(2, B, 3, frame1s.shape[2], 3).unbind(0)]   # [direction][frame] -> (B,N1,3)
+            src6 = torch.cat([lv1[0][0], lv1[0][1], lv1[0][2], lv1[1][2], lv1[1][1], lv1[1][0]], dim=0)
             rep6 = lambda t: torch.cat([t[:B]] * 3 + [t[B:]] * 3, dim=0)
             up6 = ops.backend().interp3_apply(src6.contiguous(), rep6(i3), rep6(w3))  # (6B,N,3)
-            up_f, up_b = list(up6[:3 * B].split(B)), list(up6[3 * B:].split(B))
+            up6 = list(up6.split(B))
+            up_f, up_b = up6[:3], up6[3:]
             up_flow = torch.cat([up_f[0], up_f[1], up_b[2]], dim=0)
         else:
             flow_src = frame1s                                                     # (3B,N1,3): the three flows read below
@@ -1281,12 +1284,13 @@ class MoCoPCI(nn.Module):
             return out_lst
         # the lists the training loss reads (mocopci.py:1011-1059), all (B,n,3): index i = interpolated frame
         p1, p2 = [p[:B] for p in pcs], [p[B:] for p in pcs]
-        lv = {1: frame1s, 2: frame2s, 3: frame3s}                                  # (2B,3,N_l,3): [:B] forward, [B:] backward
+        per = lambda t: [d.unbind(1) for d in t.reshape(2, B, 3, t.shape[2], 3).unbind(0)]   # (2B,3,N_l,3) -> [direction][frame] (B,N_l,3)
+        lv = {1: lv1, 2: per(frame2s), 3: per(frame3s)}                            # direction 0 forward, 1 backward
         flows_f = [[p1[0] + up_f[i] for i in range(3)], [p1[0] + up_b[2 - i] for i in range(3)]]
         flows_b = [[p2[0] + up_b[i] for i in range(3)], [p2[0] + up_f[2 - i] for i in range(3)]]
         for l in (1, 2, 3):
-            flows_f.append([p1[l] + lv[l][:B, i] for i in range(3)])
-            flows_b.append([p2[l] + lv[l][B:, 2 - i] for i in range(3)])
+            flows_f.append([p1[l] + lv[l][0][i] for i in range(3)])
+            flows_b.append([p2[l] + lv[l][1][2 - i] for i in range(3)])
         return flows_f, flows_b, out_lst
 
     def prefetch(self, xyz1, xyz2, inputs_ready=None):

@@ -35,7 +35,7 @@ def _stacked(preds, gt_rows):
     if len(preds) == 1:
         return [ops.backend().chamfer(preds[0].contiguous(), gt_rows)]
     v = ops.backend().chamfer(torch.cat([p.contiguous() for p in preds], dim=0), gt_rows.repeat(len(preds), 1, 1), per_sample=True)
-    return [v[i * B:(i + 1) * B].mean() for i in range(len(preds))]
+    return list(v.reshape(len(preds), B).mean(dim=1).unbind(0))   # one mean and one unbind (backward: one stack), not a slice per term
 
 
 def _multiscale_loss(frames_lst_f, frames_lst_b, gt_frame, out_lst, gt):
