@@ -424,7 +424,9 @@ class MoCoPCI(nn.Module):
             f1 = self.conv1d_block(f1, p + "level1_0", like_rows=like)
         B = xyz.shape[0] // 2
         d = "multi_frame_inference."
-        swap = lambda t: torch.cat([t[B:], t[:B]], dim=0)
+        # the two frames swapped; in a training graph as a roll (its backward is a roll: two slices' are two zero-filled tensors, two copies
+        # and an add)
+        swap = lambda t: torch.roll(t, B, 0) if t.requires_grad else torch.cat([t[B:], t[:B]], dim=0)
 
         def branches(lvl, f):  # decoder work that needs nothing but this level's encoder features (both frames stacked)
             if standalone:
@@ -1074,7 +1076,7 @@ class MoCoPCI(nn.Module):
         level being computed then (the training loss reads them all)."""
         m = "multi_frame_inference."
         dev = pcs[0].device
-        sw = lambda t: torch.cat([t[B:], t[:B]], dim=0)                            # swap the two frames
+        sw = lambda t: torch.roll(t, B, 0) if t.requires_grad else torch.cat([t[B:], t[:B]], dim=0)   # swap the two frames (training graph: a roll, see run_encoder)
         sched = self._sched
         # "other" frame, same order (levels 1..3 are the ones read): the encoder issued these copies off the main stream as soon as
         # their sources existed -- the clouds with the sampling pyramid, the level-1 / 2 features on their lanes; level 3's features are
@@ -1184,7 +1186,8 @@ class MoCoPCI(nn.Module):
             f1_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n1_2[:B], n2_2[:B]], 0), cache, "21"), m + "deconv2_1")
             f2_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n2_2[B:], n1_2[B:]], 0), cache, "21"), m + "deconv2_1")
             # forward call gets (feat1_l2_1_f, feat2_l2_1_f); backward call gets (feat2_l2_1_b, feat1_l2_1_b)
-            return torch.cat([f1_up[:B], f2_up[B:]], dim=0), torch.cat([f1_up[B:], f2_up[:B]], dim=0)
+            (a0, a1), (b0, b1) = (t.reshape(2, B, *t.shape[1:]).unbind(0) for t in (f1_up, f2_up))   # halves by unbind (backward: a stack)
+            return torch.cat([a0, b1], dim=0), torch.cat([a1, b0], dim=0)
         fus[1] = sched.get(("fus", 1))
         if proj:
             self.interp_prepare(pcs[1], pcs[2], cache, "21")
