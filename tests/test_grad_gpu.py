@@ -594,10 +594,27 @@ def test_linear_weight_gradient_kernel_matches_float64_and_repeats(rows, n, k):
     assert lib.mcp_linear_wgrad_workspace_bytes(1000, 512, 32) == 0     # shapes the kernel does not take report 0: the caller keeps the GEMM
 
 
-def test_chamfer_gradients():
-    x, y = cloud(80, 2, 500), cloud(81, 2, 700)
+@pytest.mark.parametrize("n,m", [(500, 700), (4096, 2048)])
+def test_chamfer_gradients(n, m):
+    """The explicit backward (ops._ChamferFn: search distances forward, direct term minus the other direction's scattered term backward)
+    against torch autograd over the oracle backend's dense form; per-sample values; a ground truth that asks for no gradient; the
+    same bits on every call; and against autograd over the unfused twin on the device."""
+    x, y = cloud(80, 2, n), cloud(81, 2, m)
     ob, be = OracleBackend(), ops.backend()
     compare_grads(lambda a, b: be.chamfer(a, b), lambda a, b: ob.chamfer(a, b), [x, y], names=["x", "y"])
+    w = torch.tensor([0.3, 1.7])
+    compare_grads(lambda a, b: (be.chamfer(a, b, per_sample=True) * w.to(DEV)).sum(), lambda a, b: (ob.chamfer(a, b, per_sample=True) * w).sum(), [x, y],
+                  names=["x", "y"])
+    xd, yd = x.to(DEV).requires_grad_(True), y.to(DEV)
+    g1 = torch.autograd.grad(be.chamfer(xd, yd), xd)[0]
+    g2 = torch.autograd.grad(be.chamfer(xd, yd), xd)[0]
+    assert torch.equal(g1, g2)
+    be.EXPLICIT_CHAMFER_GRAD = False
+    try:
+        g3 = torch.autograd.grad(be.chamfer(xd, yd), xd)[0]
+    finally:
+        be.EXPLICIT_CHAMFER_GRAD = True
+    torch.testing.assert_close(g1, g3, rtol=1e-4, atol=1e-6 * float(g3.abs().max()) + 1e-9)
 
 
 @pytest.mark.parametrize("module_mode", ["eval", "train"])
