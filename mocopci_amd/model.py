@@ -240,14 +240,25 @@ class MoCoPCI(nn.Module):
         mean = flat.mean(dim=1)
         var = flat.var(dim=1, unbiased=False)
         with torch.no_grad():
+            # G momentum updates in sequence, r <- (1 - m) r + m s_g, in closed form: r <- (1 - m)^G r + sum_g m (1 - m)^(G-1-g) s_g
+            # (one matrix-vector product per statistic instead of 2 G tiny in-place kernels)
             rm, rv, m = P[name + ".running_mean"], P[name + ".running_var"], self.BN_MOMENTUM
-            for g in range(G):
-                rm.mul_(1.0 - m).add_(mean[g], alpha=m)
-                rv.mul_(1.0 - m).add_(var[g], alpha=m * n / (n - 1))
+            coef, keep = self.ema_coefficients(G, m, x.device)
+            rm.mul_(keep).add_(coef @ mean.detach())
+            rv.mul_(keep).add_(coef @ var.detach(), alpha=n / (n - 1))
             P[name + ".num_batches_tracked"].add_(G)
         shape = (G,) + (1,) * (x.dim() - 2) + (C,)
         scale = P[name + ".weight"] * torch.rsqrt(var + eps)
         return (x - mean.reshape(shape)) * scale.reshape(shape) + P[name + ".bias"]
+
+    def ema_coefficients(self, G, m, device):
+        """(coef (G,), keep) of G momentum updates in sequence: r <- keep r + coef @ s; the device tensor is built once (a host-to-device
+        copy inside a forward would stall the stream)."""
+        key = ("ema", G, m, str(device))
+        cache = self.__dict__.setdefault("_time_cache", {})
+        if key not in cache:
+            cache[key] = torch.tensor([m * (1.0 - m) ** (G - 1 - g) for g in range(G)], dtype=torch.float32, device=device)
+        return cache[key], (1.0 - m) ** G
 
     def norm(self, x, name, eps):
         """The block's BatchNorm on (samples, ..., C): batch statistics per sample in a net.train() training forward, the running
@@ -996,21 +1007,25 @@ class MoCoPCI(nn.Module):
             aff = [t for _, bi in layers for t in (P[m + f"{bi}.weight"], P[m + f"{bi}.bias"])]
             per = p1.shape[0] // calls
             rows = per * p1.shape[1] * 64
-            outs = []
+            outs, stats = [], []
             for c in range(calls):
                 sl = slice(c * per, (c + 1) * per)
                 idx_c = tuple(i[sl] for i in idx) if isinstance(idx, (tuple, list)) else idx[sl]
                 out, bn, var = be.fusion_bn(p1[sl], p2[sl], idx_c, conv, aff, 1e-3)
                 outs.append(out)
-                with torch.no_grad():
-                    at_bn = at_var = 0
-                    for (_, bi), ch in zip(layers, (64, 64, 128)):
-                        rm, rv, mom = P[m + f"{bi}.running_mean"], P[m + f"{bi}.running_var"], self.BN_MOMENTUM
-                        rm.mul_(1.0 - mom).add_(bn[at_bn:at_bn + ch], alpha=mom)
-                        rv.mul_(1.0 - mom).add_(var[at_var:at_var + ch], alpha=mom * rows / (rows - 1))
-                        P[m + f"{bi}.num_batches_tracked"].add_(1)
-                        at_bn += 4 * ch
-                        at_var += ch
+                stats.append((bn, var))
+            with torch.no_grad():
+                # the calls' momentum updates in sequence, in closed form (bn_batch): one product per layer and statistic
+                mom = self.BN_MOMENTUM
+                coef, keep = self.ema_coefficients(calls, mom, p1.device)
+                bns, vrs = torch.stack([b for b, _ in stats]), torch.stack([v for _, v in stats])     # (calls, 1024), (calls, 256)
+                at_bn = at_var = 0
+                for (_, bi), ch in zip(layers, (64, 64, 128)):
+                    P[m + f"{bi}.running_mean"].mul_(keep).add_(coef @ bns[:, at_bn:at_bn + ch])
+                    P[m + f"{bi}.running_var"].mul_(keep).add_(coef @ vrs[:, at_var:at_var + ch], alpha=rows / (rows - 1))
+                    P[m + f"{bi}.num_batches_tracked"].add_(calls)
+                    at_bn += 4 * ch
+                    at_var += ch
             return torch.cat(outs, dim=0)
         idx = grad.whole(idx)
         if p1.shape[0] * p1.shape[1] * idx.shape[-1] * 128 * 4 <= self.CHECKPOINT_BYTES or not torch.is_grad_enabled():
