@@ -29,29 +29,50 @@ def multiscale_loss(frames_lst_f, frames_lst_b, gt_frame, out_lst, gt):
 
 
 def _stacked(preds, gt_rows):
-    """Chamfer of every prediction in `preds` (each (B,n,3)) against the same ground-truth cloud (B,m,3): [mean over B] per prediction."""
+    """Chamfer of every prediction in `preds` (each (B,n,3)) against the same ground-truth cloud (B,m,3): a (len(preds),) tensor, the
+    mean over B per prediction -- one call on the stacked batch."""
     import torch
     B = preds[0].shape[0]
     if len(preds) == 1:
-        return [ops.backend().chamfer(preds[0].contiguous(), gt_rows)]
+        return ops.backend().chamfer(preds[0].contiguous(), gt_rows).reshape(1)
     v = ops.backend().chamfer(torch.cat([p.contiguous() for p in preds], dim=0), gt_rows.repeat(len(preds), 1, 1), per_sample=True)
-    return list(v.reshape(len(preds), B).mean(dim=1).unbind(0))   # one mean and one unbind (backward: one stack), not a slice per term
+    return v.reshape(len(preds), B).mean(dim=1)   # one mean (backward: one expand), not a slice per term
+
+
+_weights = {}   # (signature, device) -> (total weights (T,), part weights (5,T)) on the device, built once
 
 
 def _multiscale_loss(frames_lst_f, frames_lst_b, gt_frame, out_lst, gt):
+    """The terms as ONE vector t (in the order below) and the objective as one dot product with a constant weight vector -- the
+    reference's nested sums (train.py:135-160) are 70 scalar adds and multiplies, each an autograd node with a launch of its own:
+        final      sum of the terms of out_lst                                  weight 1     in the total
+        straight   0.5 (f0 + f1) per triple, forward and backward               weight 1/2
+        multi      ALPHA[l+1] x term per triple and level, forward and backward weight 1/4"""
+    import torch
     rows = lambda g: g.transpose(1, 2).contiguous()   # (B,3,n) as train.py holds the ground truth -> (B,n,3)
-    loss_f = sum(_stacked([frames], rows(g))[0] for frames, g in zip(out_lst, gt))
-    loss_s_f = loss_s_b = loss_m_f = loss_m_b = 0.0
+    vals, spec = [], []                               # spec: (part index, weight inside the part) per term
+    for frames, g in zip(out_lst, gt):
+        vals.append(_stacked([frames], rows(g)))
+        spec.append((0, 1.0))
     for frames_f, frames_b, gts in zip(frames_lst_f, frames_lst_b, gt_frame):
-        f0, f1, b0, b1 = _stacked([frames_f[0], frames_f[1], frames_b[0], frames_b[1]], rows(gts[0]))
-        loss_s_f = loss_s_f + 0.5 * f0 + 0.5 * f1
-        loss_s_b = loss_s_b + 0.5 * b0 + 0.5 * b1
+        vals.append(_stacked([frames_f[0], frames_f[1], frames_b[0], frames_b[1]], rows(gts[0])))
+        spec += [(1, 0.5), (1, 0.5), (2, 0.5), (2, 0.5)]
         for l in range(len(ALPHA) - 1):
-            mf, mb = _stacked([frames_f[l + 2], frames_b[l + 2]], rows(gts[l + 1]))
-            loss_m_f = loss_m_f + ALPHA[l + 1] * mf
-            loss_m_b = loss_m_b + ALPHA[l + 1] * mb
-    total = loss_f + (loss_s_f + loss_s_b) / 2 + 0.25 * loss_m_b + 0.25 * loss_m_f
-    return total, {"final": loss_f, "straight_f": loss_s_f, "straight_b": loss_s_b, "multi_f": loss_m_f, "multi_b": loss_m_b}
+            vals.append(_stacked([frames_f[l + 2], frames_b[l + 2]], rows(gts[l + 1])))
+            spec += [(3, ALPHA[l + 1]), (4, ALPHA[l + 1])]
+    t = torch.cat(vals)
+    key = (tuple(spec), str(t.device))
+    if key not in _weights:
+        in_total = (1.0, 0.5, 0.5, 0.25, 0.25)        # final, straight_f, straight_b, multi_f, multi_b
+        parts_w = torch.zeros(5, len(spec))
+        for i, (k, w) in enumerate(spec):
+            parts_w[k, i] = w
+        total_w = (torch.tensor(in_total).unsqueeze(1) * parts_w).sum(0)
+        _weights[key] = (total_w.to(t.device), parts_w.to(t.device))
+    total_w, parts_w = _weights[key]
+    total = torch.dot(t, total_w)
+    parts = parts_w @ t.detach()
+    return total, {"final": parts[0], "straight_f": parts[1], "straight_b": parts[2], "multi_f": parts[3], "multi_b": parts[4]}
 
 
 def train_step(net, optimizer, xyz1, xyz2, gt, clip=2.0):
