@@ -251,6 +251,15 @@ class MoCoPCI(nn.Module):
         scale = P[name + ".weight"] * torch.rsqrt(var + eps)
         return (x - mean.reshape(shape)) * scale.reshape(shape) + P[name + ".bias"]
 
+    @staticmethod
+    def halves(t):
+        """(t[:h], t[h:]) of a tensor stacked along axis 0.  In a training graph as ONE unbind of the (2, h, ...) view: its backward is
+        one stack, two slices' are two zero-filled tensors, two copies and an add."""
+        h = t.shape[0] // 2
+        if t.requires_grad and torch.is_grad_enabled():
+            return t.reshape(2, h, *t.shape[1:]).unbind(0)
+        return t[:h], t[h:]
+
     def ema_coefficients(self, G, m, device):
         """(coef (G,), keep) of G momentum updates in sequence: r <- keep r + coef @ s; the device tensor is built once (a host-to-device
         copy inside a forward would stall the stream)."""
@@ -443,7 +452,7 @@ class MoCoPCI(nn.Module):
             if standalone:
                 return
             sched.run(("swap_f", lvl), lambda: swap(f))   # the "other frame" arrangement the decoder reads
-            sched.run(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", f[:B], f[B:], stacked=f)))
+            sched.run(("fus", lvl), lambda: (lambda g: torch.cat([g, g], dim=0))(self.ei_crossformer(d + f"ei{lvl}", *self.halves(f), stacked=f)))
             def cos():  # both directions of the feature-space search: the backward one is the forward one with its halves swapped
                 i12 = ops.backend().knn_cosine(f, sched.get(("swap_f", lvl)), 16)   # the swapped copy made by the node above (same lane in the shipped table: no wait)
                 return i12, swap(i12)
@@ -1113,7 +1122,7 @@ class MoCoPCI(nn.Module):
             # beside the level-0 interpolation search, long before this stream wants them
             def rep0():
                 i3_, w3_ = sched.get("i3_01")
-                r3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
+                r3 = lambda t: (lambda a, b: torch.cat([a, a, b], dim=0))(*self.halves(t))
                 return r3(pcs[0]), r3(feats[0]), r3(i3_), r3(w3_)
             sched.run("rep0", rep0)
 
@@ -1126,7 +1135,7 @@ class MoCoPCI(nn.Module):
         f3o = feats_o[3]
         sched.run("up43", up43)
         sched.run(("cos", 3), lambda: ops.backend().knn_cosine(feats[3], f3o, 16))
-        f3 = self.ei_crossformer(m + "ei3", feats[3][:B], feats[3][B:], stacked=feats[3])
+        f3 = self.ei_crossformer(m + "ei3", *self.halves(feats[3]), stacked=feats[3])
         fus = [None, None, None, None]
 
         self._mark("ei3 done")
@@ -1155,7 +1164,7 @@ class MoCoPCI(nn.Module):
                                                                torch.stack([self.Bv(x + ".cross_t1"), self.Bv(x + ".cross_t2")]).unsqueeze(1).contiguous()))
             new3 = torch.baddbmm(bt, new3.reshape(2, -1, new3.shape[-1]), wt).reshape(new3.shape[0], new3.shape[1], -1)
         else:
-            new3 = torch.cat([self.lin(new3[:B], x + ".cross_t1"), self.lin(new3[B:], x + ".cross_t2")], dim=0)
+            new3 = (lambda a, b: torch.cat([self.lin(a, x + ".cross_t1"), self.lin(b, x + ".cross_t2")], dim=0))(*self.halves(new3))
         # Feature-only chains (upsampled features -> deconv -> the four projections of the next Multiframe_Attention) are schedule nodes
         # of their own -- their lane has been idle since the encoder -- beside this stream's coordinate chain (cross_block3 / flow
         # upsampling / warp / searches): both are rows of small launches that leave the chip mostly empty.  The 3-NN search both
@@ -1198,8 +1207,9 @@ class MoCoPCI(nn.Module):
         # l2 -> l1 (mocopci.py:920-927): the forward branch upsamples (feat1_new_f -> pc1, feat2_new_f -> pc2),
         # the backward branch (feat1_new_b -> pc1, feat2_new_b -> pc2) where *_b come from the swapped call.
         def upsampled1():
-            f1_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n1_2[:B], n2_2[:B]], 0), cache, "21"), m + "deconv2_1")
-            f2_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n2_2[B:], n1_2[B:]], 0), cache, "21"), m + "deconv2_1")
+            (n1f, n1b), (n2f, n2b) = self.halves(n1_2), self.halves(n2_2)
+            f1_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n1f, n2f], 0), cache, "21"), m + "deconv2_1")
+            f2_up = self.conv1d_block(self.interp(pcs[1], pcs[2], torch.cat([n2b, n1b], 0), cache, "21"), m + "deconv2_1")
             # forward call gets (feat1_l2_1_f, feat2_l2_1_f); backward call gets (feat2_l2_1_b, feat1_l2_1_b)
             (a0, a1), (b0, b1) = (t.reshape(2, B, *t.shape[1:]).unbind(0) for t in (f1_up, f2_up))   # halves by unbind (backward: a stack)
             return torch.cat([a0, b1], dim=0), torch.cat([a1, b0], dim=0)
@@ -1221,7 +1231,7 @@ class MoCoPCI(nn.Module):
         frame1s = self.multiframe_attention(m + "multi_frame_up_1", pcs[1], pcs_o[1], f_up_1, f_up_1_o, feats[1], fus[1],
                                             feats_o[1], fus[1], ups, te, rows=rows1, idx_c12=sched.get(("cos", 1)),
                                             projections=("mfa_proj", 1) if proj else None)[0].contiguous()
-        rep3 = lambda t: torch.cat([t[:B], t[:B], t[B:]], dim=0)
+        rep3 = lambda t: (lambda a, b: torch.cat([a, a, b], dim=0))(*self.halves(t))
         # the three refinements interpolate on (pc1->pc1, pc1->pc1, pc2->pc2): one 3-NN search on the stacked frames
         # (2B rows), its rows repeated for the 3B arrangement
         if train:
@@ -1235,7 +1245,7 @@ class MoCoPCI(nn.Module):
             # (unbind, not six slices: its backward is one stack, a slice's is a zero-filled tensor plus a copy)
             lv1 = [d.unbind(1) for d in frame1s.reshape(2, B, 3, frame1s.shape[2], 3).unbind(0)]   # [direction][frame] -> (B,N1,3)
             src6 = torch.cat([lv1[0][0], lv1[0][1], lv1[0][2], lv1[1][2], lv1[1][1], lv1[1][0]], dim=0)
-            rep6 = lambda t: torch.cat([t[:B]] * 3 + [t[B:]] * 3, dim=0)
+            rep6 = lambda t: (lambda a, b: torch.cat([a] * 3 + [b] * 3, dim=0))(*self.halves(t))
             up6 = ops.backend().interp3_apply(src6.contiguous(), rep6(i3), rep6(w3))  # (6B,N,3)
             up6 = list(up6.split(B))
             up_f, up_b = up6[:3], up6[3:]
@@ -1297,7 +1307,7 @@ class MoCoPCI(nn.Module):
         self._mark("refine coords done")
         final = self.fusion(warped, refine, idx_self=idx_self, calls=3)
         self._mark("fusion done")
-        out_lst = [final[:B], final[B:2 * B], final[2 * B:]]
+        out_lst = list(final.split(B))
         if not train:
             return out_lst
         # the lists the training loss reads (mocopci.py:1011-1059), all (B,n,3): index i = interpolated frame
