@@ -278,6 +278,20 @@ int mcp_fusion_bn_backward(int b, int n, int nb, const float *p1, const float *p
                            float *row_dy, float *row_a, float *dy2, float *dy1, float *grad_p1, float *grad_nb, float *grad_weights,
                            float *grad_affine, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
 
+/* The pair that keeps what the backward's first pass would otherwise re-evaluate the whole layer for: per (point, neighbour) row
+ * (rows = b * n * 64) the neighbour's score (the maximum over the layer-3 channels, floored at 0), the channel it sits at and zhat3 there
+ * -- save_c (int32), save_z, save_s (floats), caller-owned, 12 bytes per row.  mcp_fusion_bn_forward_save = mcp_fusion_bn_forward + these
+ * outputs (same out / bn / var bit for bit); mcp_fusion_bn_backward_saved = mcp_fusion_bn_backward with a first pass that reads them
+ * (same gradients bit for bit). */
+int mcp_fusion_bn_forward_save(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1,
+                               const float *w2, const float *b2, const float *w3, const float *b3, float eps, float *bn, float *var, float *out, int *save_c,
+                               float *save_z, float *save_s, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+int mcp_fusion_bn_backward_saved(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1,
+                                 const float *w2, const float *b2, const float *w3, const float *b3, const float *bn, const float *grad_out,
+                                 const int *save_c, const float *save_z, const float *save_s, int *row_c, float *row_dy, float *row_a, float *dy2, float *dy1,
+                                 float *grad_p1, float *grad_nb, float *grad_weights, float *grad_affine, void *workspace, size_t workspace_bytes,
+                                 mcp_stream_t stream);
+
 /* Cost-volume cross() after its neighbour searches (pointconv_util.py:750-781, :894-922, :1126-1161):
  * xyz1 (B,N1,3), xyz2 (B,N2,3), points1 (B,N1,D), points2 (B,N2,D) channel-last (16-byte aligned),
  * idx (B,N1,32) int32 into set 2 (16 feature-cosine + 16 xyz neighbours) -> out (B,N1,D) = max over the 32

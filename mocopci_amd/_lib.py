@@ -58,6 +58,8 @@ SIGNATURES = {
     "mcp_fusion_bn_forward": [_i, _i, _i] + [_p] * 10 + [_f] + [_p] * 4 + [ctypes.c_size_t, _p],
     "mcp_fusion_bn_grad_workspace_bytes": [_i, _i],
     "mcp_fusion_bn_backward": [_i, _i, _i] + [_p] * 22 + [ctypes.c_size_t, _p],
+    "mcp_fusion_bn_forward_save": [_i, _i, _i] + [_p] * 10 + [_f] + [_p] * 7 + [ctypes.c_size_t, _p],
+    "mcp_fusion_bn_backward_saved": [_i, _i, _i] + [_p] * 25 + [ctypes.c_size_t, _p],
     "mcp_cross_packed_floats": [_i],
     "mcp_cross_pack": [_i, _p, _p, _p, _p, _p, _p],
     "mcp_cross_volume": [_i] * 5 + [_p] * 7 + [_i, _p, _p, _p],

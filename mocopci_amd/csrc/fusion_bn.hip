@@ -110,14 +110,18 @@ __device__ __forceinline__ f32x16 bias_tile(const float *lds, int off) {
     return acc;
 }
 
-// MODE 1 / 2 / 3: sums of W h and (W h)^2 of layer MODE over all rows (partial[blockIdx][2 C]); MODE 0: the layer -> out (B,N,3)
-template <int MODE>
+// MODE 1 / 2 / 3: sums of W h and (W h)^2 of layer MODE over all rows (partial[blockIdx][2 C]); MODE 0: the layer -> out (B,N,3).
+// SAVE (MODE 0): also every neighbour's score (the maximum over the channels of the layer-3 output, floored at 0), the channel it sits at
+// and zhat3 there -- what the backward's first pass (fusion_bn_b1_kernel) re-evaluates the whole layer for; with them it is a light
+// kernel (fusion_bn_b1_saved_kernel).  The maximum is tracked exactly as that pass does (strict >, lowest channel among equals).
+template <int MODE, bool SAVE = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_fwd_kernel(long long total, int n, const float *__restrict__ p1, const float *__restrict__ p2,
                                                                    const int *__restrict__ idx, const int *__restrict__ idx2,
                                                                    const float *__restrict__ w1, const float *__restrict__ b1,
                                                                    const float *__restrict__ w2, const float *__restrict__ b2,
                                                                    const float *__restrict__ w3, const float *__restrict__ b3,
-                                                                   const float *__restrict__ bn, float *__restrict__ out) {
+                                                                   const float *__restrict__ bn, float *__restrict__ out, int *__restrict__ save_c,
+                                                                   float *__restrict__ save_z, float *__restrict__ save_s) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     uint4 *w2s = reinterpret_cast<uint4 *>(lds + L_F32);
     uint4 *w3s = w2s + W2_U4;
@@ -184,7 +188,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_fwd_kernel(long long 
                 }
             }
             if (MODE == 2) continue;
-            float m = 0.f;
+            float m = 0.f, zb = 0.f;
+            int mr = 0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 f32x16 z3 = bias_tile<MODE == 3>(lds, L_B3 + (t * 2 + h) * 16);
@@ -195,11 +200,35 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_fwd_kernel(long long 
                 } else {
                     f32x16 zh, v;
                     bn_tile<C3>(lds + L_BN3 + (t * 2 + h) * 16, z3, zh, v);
+                    if (SAVE) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m = fmaxf(m, v[r]);
+                        for (int r = 0; r < 16; ++r) {
+                            const bool up = v[r] > m;
+                            m = up ? v[r] : m;
+                            zb = up ? zh[r] : zb;
+                            mr = up ? 16 * t + r : mr;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) m = fmaxf(m, v[r]);
+                    }
                 }
             }
-            score[ct] = fmaxf(m, __shfl_xor(m, 32));
+            if (SAVE) {
+                const int mc = 32 * (mr >> 4) + chan_of(mr & 15, h);
+                const float om = __shfl_xor(m, 32), oz = __shfl_xor(zb, 32);
+                const int oc = __shfl_xor(mc, 32);
+                const bool other = om > m || (om == m && oc < mc);
+                score[ct] = other ? om : m;
+                if (h == 0) {
+                    const long long row = p * NB + 32 * ct + col;
+                    save_c[row] = other ? oc : mc;
+                    save_z[row] = other ? oz : zb;
+                    save_s[row] = score[ct];
+                }
+            } else {
+                score[ct] = fmaxf(m, __shfl_xor(m, 32));
+            }
         }
         if (MODE == 0) {
             const float mx = wave_max(fmaxf(score[0], score[1]));
@@ -283,10 +312,11 @@ unsigned fwd_grid(long long total) {
     return (unsigned)(want < cap ? want : cap);
 }
 
-template <int MODE>
+template <int MODE, bool SAVE = false>
 int launch_fwd(long long total, int n, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1, const float *w2,
-               const float *b2, const float *w3, const float *b3, const float *bn, float *out, unsigned grid, hipStream_t s) {
-    auto kern = fusion_bn_fwd_kernel<MODE>;
+               const float *b2, const float *w3, const float *b3, const float *bn, float *out, unsigned grid, hipStream_t s, int *save_c = nullptr,
+               float *save_z = nullptr, float *save_s = nullptr) {
+    auto kern = fusion_bn_fwd_kernel<MODE, SAVE>;
     static McpPerDeviceOnce attr_once;
     if (attr_once.need()) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -294,7 +324,7 @@ int launch_fwd(long long total, int n, const float *p1, const float *p2, const i
         attr_once.done();
     }
     const size_t lds = (size_t)L_F32 * 4 + (size_t)(W2_U4 + W3_U4) * 16;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, out);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, out, save_c, save_z, save_s);
     return mcp_launch_status();
 }
 
@@ -450,6 +480,100 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b1_kernel(long long t
             score[ct] = other ? om : m;
             zstar[ct] = other ? oz : zb;
             cstar[ct] = other ? oc : mc;
+        }
+        const float mx = wave_max(fmaxf(score[0], score[1]));
+        const float e0 = expf(score[0] - mx), e1 = expf(score[1] - mx);
+        const float den = 0.5f * wave_sum(e0 + e1);  // every neighbour sits in both lane halves
+        const float a0 = e0 / den, a1 = e1 / den;
+        const float da0 = (gx * nbx[0] + gy * nby[0]) + gz * nbz[0], da1 = (gx * nbx[1] + gy * nby[1]) + gz * nbz[1];
+        const float sdot = 0.5f * wave_sum(a0 * da0 + a1 * da1);
+        const float dy[2] = {score[0] > 0.f ? a0 * (da0 - sdot) : 0.f, score[1] > 0.f ? a1 * (da1 - sdot) : 0.f};
+        const float aw[2] = {a0, a1};
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            __builtin_amdgcn_wave_barrier();
+            if (h == 0) {
+                const long long row = p * NB + 32 * ct + col;
+                row_c[row] = cstar[ct];
+                row_dy[row] = dy[ct];
+                row_a[row] = aw[ct];
+                csb[col] = cstar[ct];
+                dzb[col] = dy[ct];
+                ezb[col] = dy[ct] * zstar[ct];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int j0 = 16 * ks + 8 * h;
+                const int4 ca = reinterpret_cast<const int4 *>(csb + j0)[0], cb = reinterpret_cast<const int4 *>(csb + j0)[1];
+                const int cs8[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+                float dz8[8], ez8[8];
+                mcp_read8(dzb + j0, dz8);
+                mcp_read8(ezb + j0, ez8);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int c = 32 * mt + col;
+                    float s = 0.f, g = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        s += cs8[i] == c ? dz8[i] : 0.f;
+                        g += cs8[i] == c ? ez8[i] : 0.f;
+                    }
+                    sb[mt] += s;
+                    sg[mt] += g;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float *red = lds;  // [WAVES][256]: sum dy3' (128) | sum dy3' zhat3 (128), natural channel order
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const float a = sb[mt] + __shfl_xor(sb[mt], 32), b = sg[mt] + __shfl_xor(sg[mt], 32);
+        if (h == 0) {
+            red[wave * 256 + 32 * mt + col] = a;
+            red[wave * 256 + 128 + 32 * mt + col] = b;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        float v = red[tid];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) v += red[w * 256 + tid];
+        partial[(size_t)blockIdx.x * 256 + tid] = v;
+    }
+}
+
+// ---- B1 with the forward's per-neighbour (score, c*, zhat3 at c*) saved (mcp_fusion_bn_forward_save): no layer to re-evaluate -- the
+// softmax over the 64 scores, ds, the per-row outputs and the two per-channel sums, exactly as above from its `score / zstar / cstar` on ----
+__global__ __launch_bounds__(64 * WAVES, 2) void fusion_bn_b1_saved_kernel(long long total, int n, const float *__restrict__ p2, const int *__restrict__ idx,
+                                                                        const int *__restrict__ idx2, const float *__restrict__ gout,
+                                                                        const int *__restrict__ save_c, const float *__restrict__ save_z,
+                                                                        const float *__restrict__ save_s, int *__restrict__ row_c,
+                                                                        float *__restrict__ row_dy, float *__restrict__ row_a, float *__restrict__ partial) {
+    __shared__ float lds[WAVES * 256];   // the per-wave scratch first, the reduction buffer afterwards
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, col = lane & 31;
+    float *scr = lds + wave * B1_SCR;
+    int *csb = reinterpret_cast<int *>(scr);
+    float *dzb = scr + 32, *ezb = scr + 64;
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};  // lane = channel 32 mt + col
+
+    const McpUnits units = mcp_units_by_xcd(total, WAVES);   // the same points per workgroup as fusion_bn_b1_kernel: the same summation order
+    for (long long p = units.first + wave; p < units.limit; p += units.stride) {
+        const long long bb = mcp_div(p, n, mcp_fits32(total));
+        const float gx = gout[p * 3 + 0], gy = gout[p * 3 + 1], gz = gout[p * 3 + 2];
+        float score[2], zstar[2], nbx[2], nby[2], nbz[2];
+        int cstar[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int id = idx2 ? (ct ? idx2 : idx)[p * 32 + col] : idx[p * NB + 32 * ct + col];
+            const float *q = p2 + ((long long)bb * n + id) * 3;
+            nbx[ct] = q[0]; nby[ct] = q[1]; nbz[ct] = q[2];
+            const long long row = p * NB + 32 * ct + col;
+            score[ct] = save_s[row];
+            zstar[ct] = save_z[row];
+            cstar[ct] = save_c[row];
         }
         const float mx = wave_max(fmaxf(score[0], score[1]));
         const float e0 = expf(score[0] - mx), e1 = expf(score[1] - mx);
@@ -1008,9 +1132,33 @@ MCP_EXPORT size_t mcp_fusion_bn_workspace_bytes(int b, int n) {
 // The layer on BATCH statistics, forward.  bn (1024 floats): per layer mean | rstd | gamma | beta, natural channel order, layers
 // 4 -> 64 -> 64 -> 128; the caller fills gamma and beta, this call fills mean and rstd (from the b clouds it is given: one
 // reference call = one set of statistics) and writes the biased variances to var (64 | 64 | 128 floats) for the running estimates.
+namespace {
+int bn_forward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1, const float *w2,
+               const float *b2, const float *w3, const float *b3, float eps, float *bn, float *var, float *out, int *save_c, float *save_z, float *save_s,
+               void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+}
+
 MCP_EXPORT int mcp_fusion_bn_forward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1,
                                      const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float eps, float *bn, float *var,
                                      float *out, void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
+    return bn_forward(b, n, nb, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, eps, bn, var, out, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+// The same forward that also keeps, per (point, neighbour) row (rows = b * n * 64), the neighbour's score, the layer-3 channel it comes
+// from and zhat3 there: save_c (int32), save_z, save_s (floats), caller-owned -- mcp_fusion_bn_backward_saved then skips the
+// re-evaluation of the whole layer in its first pass.
+MCP_EXPORT int mcp_fusion_bn_forward_save(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1,
+                                          const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float eps, float *bn,
+                                          float *var, float *out, int *save_c, float *save_z, float *save_s, void *workspace, size_t workspace_bytes,
+                                          mcp_stream_t stream) {
+    MCP_CHECK_ARGS(save_c && save_z && save_s);
+    return bn_forward(b, n, nb, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, eps, bn, var, out, save_c, save_z, save_s, workspace, workspace_bytes, stream);
+}
+
+namespace {
+int bn_forward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1, const float *w2,
+               const float *b2, const float *w3, const float *b3, float eps, float *bn, float *var, float *out, int *save_c, float *save_z, float *save_s,
+               void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && p1 && p2 && idx && w1 && b1 && w2 && b2 && w3 && b3 && bn && var && out && workspace);
     if (nb != NB) return MCP_ERR_UNSUPPORTED;
     const long long total = (long long)b * n;
@@ -1029,10 +1177,12 @@ MCP_EXPORT int mcp_fusion_bn_forward(int b, int n, int nb, const float *p1, cons
     rc = launch_fwd<3>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, partial, grid, s);
     if (rc) return rc;
     hipLaunchKernelGGL(fusion_bn_stats_kernel, dim3(C3 / 16), dim3(256), 0, s, partial, (int)grid, C3, rows, b3, eps, bn + BN_L3, var + C1 + C2);
-    rc = launch_fwd<0>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, out, grid, s);
+    rc = save_c ? launch_fwd<0, true>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, out, grid, s, save_c, save_z, save_s)
+                : launch_fwd<0>(total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, out, grid, s);
     mcp_prof_end(MCP_KERNEL_FUSION, s);
     return rc;
 }
+}  // namespace
 
 MCP_EXPORT size_t mcp_fusion_bn_grad_workspace_bytes(int b, int n) {
     if (b <= 0 || n <= 0) return 0;
@@ -1044,11 +1194,38 @@ MCP_EXPORT size_t mcp_fusion_bn_grad_workspace_bytes(int b, int n) {
 // (B,N,3), grad_nb (B,N,64,3) (for the caller's scatter into dL/dp2), grad_weights (12800 floats, mcp_fusion_grad's layout; the
 // conv-bias entries are 0: a bias in front of a batch-statistics BatchNorm has no gradient) and grad_affine (512 floats: per layer
 // dgamma | dbeta -- 64 | 64, 64 | 64, 128 | 128).
+namespace {
+int bn_backward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1, const float *w2,
+                const float *b2, const float *w3, const float *b3, const float *bn, const float *grad_out, const int *save_c, const float *save_z,
+                const float *save_s, int *row_c, float *row_dy, float *row_a, float *dy2, float *dy1, float *grad_p1, float *grad_nb, float *grad_weights,
+                float *grad_affine, void *workspace, size_t workspace_bytes, mcp_stream_t stream);
+}
+
 MCP_EXPORT int mcp_fusion_bn_backward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1,
                                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, const float *bn,
                                       const float *grad_out, int *row_c, float *row_dy, float *row_a, float *dy2, float *dy1, float *grad_p1,
                                       float *grad_nb, float *grad_weights, float *grad_affine, void *workspace, size_t workspace_bytes,
                                       mcp_stream_t stream) {
+    return bn_backward(b, n, nb, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, grad_out, nullptr, nullptr, nullptr, row_c, row_dy, row_a, dy2, dy1, grad_p1,
+                       grad_nb, grad_weights, grad_affine, workspace, workspace_bytes, stream);
+}
+
+// mcp_fusion_bn_backward with what mcp_fusion_bn_forward_save kept: the first pass reads (score, c*, zhat3) instead of re-evaluating the layer.
+MCP_EXPORT int mcp_fusion_bn_backward_saved(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1,
+                                            const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, const float *bn,
+                                            const float *grad_out, const int *save_c, const float *save_z, const float *save_s, int *row_c, float *row_dy,
+                                            float *row_a, float *dy2, float *dy1, float *grad_p1, float *grad_nb, float *grad_weights, float *grad_affine,
+                                            void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
+    MCP_CHECK_ARGS(save_c && save_z && save_s);
+    return bn_backward(b, n, nb, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, grad_out, save_c, save_z, save_s, row_c, row_dy, row_a, dy2, dy1, grad_p1,
+                       grad_nb, grad_weights, grad_affine, workspace, workspace_bytes, stream);
+}
+
+namespace {
+int bn_backward(int b, int n, int nb, const float *p1, const float *p2, const int *idx, const int *idx2, const float *w1, const float *b1, const float *w2,
+                const float *b2, const float *w3, const float *b3, const float *bn, const float *grad_out, const int *save_c, const float *save_z,
+                const float *save_s, int *row_c, float *row_dy, float *row_a, float *dy2, float *dy1, float *grad_p1, float *grad_nb, float *grad_weights,
+                float *grad_affine, void *workspace, size_t workspace_bytes, mcp_stream_t stream) {
     MCP_CHECK_ARGS(b > 0 && n > 0 && p1 && p2 && idx && w1 && b1 && w2 && b2 && w3 && b3 && bn && grad_out && row_c && row_dy && row_a && dy2 && dy1 &&
                    grad_p1 && grad_nb && grad_weights && grad_affine && workspace);
     if (nb != NB) return MCP_ERR_UNSUPPORTED;
@@ -1079,8 +1256,12 @@ MCP_EXPORT int mcp_fusion_bn_backward(int b, int n, int nb, const float *p1, con
     {   // B1
         const unsigned grid = bwd_grid(total, 2);
         const size_t lds = (size_t)L_F32 * 4 + (size_t)(W2_U4 + W3_U4) * 16 + (size_t)WAVES * B1_SCR * 4;
-        hipLaunchKernelGGL(fusion_bn_b1_kernel, dim3(grid), dim3(64 * WAVES), lds, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, grad_out, row_c,
-                           row_dy, row_a, partial);
+        if (save_c)
+            hipLaunchKernelGGL(fusion_bn_b1_saved_kernel, dim3(grid), dim3(64 * WAVES), 0, s, total, n, p2, idx, idx2, grad_out, save_c, save_z, save_s, row_c,
+                               row_dy, row_a, partial);
+        else
+            hipLaunchKernelGGL(fusion_bn_b1_kernel, dim3(grid), dim3(64 * WAVES), lds, s, total, n, p1, p2, idx, idx2, w1, b1, w2, b2, w3, b3, bn, grad_out, row_c,
+                               row_dy, row_a, partial);
         hipLaunchKernelGGL(sum_partials_kernel, dim3(16), dim3(256), 0, s, partial, (int)grid, 256, 256, sums3);
     }
     {   // B2
@@ -1113,3 +1294,4 @@ MCP_EXPORT int mcp_fusion_bn_backward(int b, int n, int nb, const float *p1, con
     mcp_prof_end(MCP_KERNEL_FUSION, s);
     return mcp_launch_status();
 }
+}  // namespace

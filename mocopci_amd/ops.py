@@ -551,14 +551,19 @@ class _FusionBNFn(torch.autograd.Function):
     def forward(ctx, be, eps, ia, ib, p1, p2, w1, b1, w2, b2, w3, b3, g1, e1, g2, e2, g3, e3):
         conv = [t.detach().contiguous() for t in (w1, b1, w2, b2, w3, b3)]
         p1, p2 = p1.detach().contiguous(), p2.detach().contiguous()
-        out, bn, var = be.fusion_bn_forward(p1, p2, ia if ib is None else (ia, ib), conv, (g1, e1, g2, e2, g3, e3), eps)
-        ctx.save_for_backward(ia, ib, p1, p2, *conv, bn)
+        rows = p1.shape[0] * p1.shape[1] * 64
+        # kept for the backward: every neighbour's score, its layer-3 channel and zhat3 there (12 bytes per row) -- the backward's first
+        # pass then has no layer to re-evaluate
+        saved = (torch.empty((rows,), dtype=torch.int32, device=p1.device), torch.empty((rows,), dtype=torch.float32, device=p1.device),
+                 torch.empty((rows,), dtype=torch.float32, device=p1.device))
+        out, bn, var = be.fusion_bn_forward(p1, p2, ia if ib is None else (ia, ib), conv, (g1, e1, g2, e2, g3, e3), eps, saved=saved)
+        ctx.save_for_backward(ia, ib, p1, p2, *conv, bn, *saved)
         ctx.mark_non_differentiable(bn, var)
         return out, bn, var
 
     @staticmethod
     def backward(ctx, grad_out, _gbn, _gvar):
-        ia, ib, p1, p2, w1, b1, w2, b2, w3, b3, bn = ctx.saved_tensors
+        ia, ib, p1, p2, w1, b1, w2, b2, w3, b3, bn, save_c, save_z, save_s = ctx.saved_tensors
         B, N, _ = p1.shape
         rows = B * N * 64
         lib, dev = _lib.load(), p1.device
@@ -572,8 +577,9 @@ class _FusionBNFn(torch.autograd.Function):
         d_aff = torch.empty((512,), dtype=torch.float32, device=dev)
         need = lib.mcp_fusion_bn_grad_workspace_bytes(B, N)
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-        _call("mcp_fusion_bn_backward", p1, B, N, 64, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib),
-              *[_lib.fptr(t) for t in (w1, b1, w2, b2, w3, b3, bn, grad_out)], _lib.iptr(row_c), _lib.fptr(row_dy), _lib.fptr(row_a), _lib.fptr(dy2),
+        _call("mcp_fusion_bn_backward_saved", p1, B, N, 64, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib),
+              *[_lib.fptr(t) for t in (w1, b1, w2, b2, w3, b3, bn, grad_out)], _lib.iptr(save_c), _lib.fptr(save_z), _lib.fptr(save_s),
+              _lib.iptr(row_c), _lib.fptr(row_dy), _lib.fptr(row_a), _lib.fptr(dy2),
               _lib.fptr(dy1), _lib.fptr(d_p1), _lib.fptr(d_nb), _lib.fptr(d_w), _lib.fptr(d_aff), ws.data_ptr(), need)
         d_p2 = None
         if ctx.needs_input_grad[5]:
@@ -838,10 +844,12 @@ class HipBackend:
             raise ValueError("fusion_bn: the batch-statistics kernels take 64 neighbours per point (2 x 32 or one list of 64)")
         return _FusionBNFn.apply(self, float(eps), ia.contiguous(), None if ib is None else ib.contiguous(), p1, p2, *conv, *affine)
 
-    def fusion_bn_forward(self, p1, p2, idx, conv, affine, eps):
+    def fusion_bn_forward(self, p1, p2, idx, conv, affine, eps, saved=None):
         """The fusion layer of ONE reference call on batch statistics (net.train(); mocopci.py:810-819 with nn.BatchNorm2d in training
         mode): conv = (w1, b1, w2, b2, w3, b3) raw conv weights, affine = (gamma1, beta1, gamma2, beta2, gamma3, beta3).
-        -> out (B,N,3), bn (1024: per layer mean | rstd | gamma | beta), var (256: biased batch variances 64 | 64 | 128).  No autograd."""
+        -> out (B,N,3), bn (1024: per layer mean | rstd | gamma | beta), var (256: biased batch variances 64 | 64 | 128).  No autograd.
+        saved: (int32, float32, float32) tensors of B*N*64 elements that receive every neighbour's arg-max channel, zhat3 there and score
+        (mcp_fusion_bn_forward_save; what mcp_fusion_bn_backward_saved reads)."""
         lib = _lib.load()
         p1, p2 = p1.contiguous(), p2.contiguous()
         conv = [t.detach().contiguous() for t in conv]
@@ -857,8 +865,13 @@ class HipBackend:
         out = torch.empty((B, N, 3), dtype=torch.float32, device=p1.device)
         need = lib.mcp_fusion_bn_workspace_bytes(B, N)
         ws = torch.empty((need,), dtype=torch.uint8, device=p1.device)
-        _call("mcp_fusion_bn_forward", p1, B, N, 64, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib),
-              *[_lib.fptr(t) for t in conv], float(eps), _lib.fptr(bn), _lib.fptr(var), _lib.fptr(out), ws.data_ptr(), need)
+        if saved is None:
+            _call("mcp_fusion_bn_forward", p1, B, N, 64, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib),
+                  *[_lib.fptr(t) for t in conv], float(eps), _lib.fptr(bn), _lib.fptr(var), _lib.fptr(out), ws.data_ptr(), need)
+        else:
+            _call("mcp_fusion_bn_forward_save", p1, B, N, 64, _lib.fptr(p1), _lib.fptr(p2), _lib.iptr(ia), None if ib is None else _lib.iptr(ib),
+                  *[_lib.fptr(t) for t in conv], float(eps), _lib.fptr(bn), _lib.fptr(var), _lib.fptr(out), _lib.iptr(saved[0]), _lib.fptr(saved[1]),
+                  _lib.fptr(saved[2]), ws.data_ptr(), need)
         return out, bn, var
 
     def _fusion_mlp(self, p1, p2, idx, w1, b1, w2, b2, w3, b3):

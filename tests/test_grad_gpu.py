@@ -313,6 +313,47 @@ def test_fusion_batch_statistics_of_a_channel_far_from_its_bias():
     assert torch.isfinite(out).all()
 
 
+def test_fusion_batch_statistics_forward_that_keeps_the_scores():
+    """mcp_fusion_bn_forward_save / mcp_fusion_bn_backward_saved: the same out / bn / var as mcp_fusion_bn_forward and the same gradients
+    as mcp_fusion_bn_backward, bit for bit -- the kept (score, arg-max channel, zhat3) rows are what the backward's first pass recomputes."""
+    import ctypes
+    from mocopci_amd import _lib
+    lib, be = _lib.load(), ops.backend()
+    B, N = 2, 700
+    p1 = cloud(190, B, N).to(DEV)
+    p2 = p1 + rnd(191, B, N, 3, scale=0.2).to(DEV)
+    ia, ib = be.knn(p1, p1, 32), be.knn(p1, p2, 32)
+    conv = [t.to(DEV) for t in (rnd(192, 64, 4, scale=0.5), rnd(193, 64, scale=0.1), rnd(194, 64, 64, scale=0.125), rnd(195, 64, scale=0.1),
+                                rnd(196, 128, 64, scale=0.125), rnd(197, 128, scale=0.1))]
+    aff = [t.to(DEV) for t in (1 + rnd(160, 64, scale=0.2), rnd(161, 64, scale=0.2), 1 + rnd(162, 64, scale=0.2), rnd(163, 64, scale=0.2),
+                               1 + rnd(164, 128, scale=0.2), rnd(165, 128, scale=0.2))]
+    rows = B * N * 64
+    saved = (torch.empty(rows, dtype=torch.int32, device=DEV), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV))
+    out0, bn0, var0 = be.fusion_bn_forward(p1, p2, (ia, ib), conv, aff, 1e-3)
+    out1, bn1, var1 = be.fusion_bn_forward(p1, p2, (ia, ib), conv, aff, 1e-3, saved=saved)
+    assert torch.equal(out0, out1) and torch.equal(bn0, bn1) and torch.equal(var0, var1)
+    assert int(saved[0].min()) >= 0 and int(saved[0].max()) < 128 and bool((saved[2] >= 0).all())
+    g = rnd(198, B, N, 3).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    need = lib.mcp_fusion_bn_grad_workspace_bytes(B, N)
+
+    def run(entry, extra):
+        scr = dict(row_c=torch.empty(rows, dtype=torch.int32, device=DEV), row_dy=torch.empty(rows, device=DEV), row_a=torch.empty(rows, device=DEV),
+                   dy2=torch.empty(rows, 64, device=DEV), dy1=torch.empty(rows, 64, device=DEV), d_p1=torch.empty_like(p1),
+                   d_nb=torch.empty(B, N, 64, 3, device=DEV), d_w=torch.empty(lib.mcp_fusion_grad_floats(), device=DEV), d_aff=torch.empty(512, device=DEV),
+                   ws=torch.empty(need, dtype=torch.uint8, device=DEV))
+        rc = getattr(lib, entry)(B, N, 64, P(p1), P(p2), P(ia), P(ib), *[P(t) for t in conv], P(bn0), P(g), *extra, P(scr["row_c"]), P(scr["row_dy"]),
+                                 P(scr["row_a"]), P(scr["dy2"]), P(scr["dy1"]), P(scr["d_p1"]), P(scr["d_nb"]), P(scr["d_w"]), P(scr["d_aff"]), P(scr["ws"]), need, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return scr
+    a = run("mcp_fusion_bn_backward", ())
+    b = run("mcp_fusion_bn_backward_saved", tuple(P(t) for t in saved))
+    for k in ("row_c", "row_dy", "row_a", "d_p1", "d_nb", "d_w", "d_aff"):
+        assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("heads,hd,nq,nk,bf", [(8, 8, 333, 517, 3), (8, 8, 2048, 2048, 2), (4, 16, 200, 64, 2), (8, 16, 130, 1000, 1)])
 def test_attention_small_backward_kernels_match_the_dense_formulation_and_repeat(heads, hd, nq, nk, bf):
     """mcp_attention_small_grad against float64 autograd over softmax(q k^T scale) v: ragged query / key counts (partial tiles on both
